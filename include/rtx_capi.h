@@ -1,0 +1,189 @@
+/*
+ * rtx_capi.h -- C ABI of the MI355X wavefront path tracer (librtx_hip.so).
+ *
+ * This is the drop-in boundary for the reference renderer's Monte-Carlo loop.
+ * The reference has no plugin or FFI interface; its seam is the call
+ * `render(img, pathTrace)` at Raytracer.cpp:319 (template render<I>,
+ * Raytracer.cpp:236-286), which reads the globals `scene` (:148), `camera`
+ * (:145), `gens` (:233) and `pos` (:235) and writes `Img::pixels` (:49).
+ * Each entry point below cites the reference code it replaces.
+ *
+ * Conventions
+ *  - Plain C: pointers and sizes only.  No C++ or torch types cross the boundary.
+ *  - Every function returns RTX_OK (0) or a negative rtx_status; it never calls
+ *    exit() (the reference does, Scene.h:66) and never throws.
+ *    rtx_last_error() returns a human-readable message for the last failure on
+ *    the calling thread.
+ *  - The library is HIP-only.  There is no CPU fallback: rtx_create fails with
+ *    RTX_ERR_NO_DEVICE when no gfx950 device is usable.
+ *  - A context is used from one thread at a time (the reference calls render()
+ *    from exactly one render thread, Raytracer.cpp:462).
+ *  - "device pointer" arguments are addresses in the memory of the context's GPU
+ *    (hipMalloc, or a torch tensor's data_ptr()).  "host pointer" arguments are
+ *    ordinary memory, borrowed only for the duration of the call.
+ *  - `stream` arguments are a hipStream_t passed as void*; NULL = the default
+ *    stream.  Calls that take a stream only enqueue work unless stated otherwise.
+ */
+#ifndef RTX_CAPI_H
+#define RTX_CAPI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  RTX_OK = 0,
+  RTX_ERR_INVALID_ARGUMENT = -1,
+  RTX_ERR_NO_DEVICE = -2,
+  RTX_ERR_HIP = -3,
+  RTX_ERR_OUT_OF_MEMORY = -4,
+  RTX_ERR_NO_SCENE = -5,
+  RTX_ERR_UNSUPPORTED = -6
+} rtx_status;
+
+/* Surface enum, Material.h:4-9 (same values). */
+enum { RTX_DIFFUSE = 0, RTX_SPECULAR = 1, RTX_REFLECTIVE = 2, RTX_VARNISH = 3 };
+
+/* struct Material, Material.h:11-15: same 20-byte layout. emission is a scalar
+ * broadcast to RGB (Integrator.h:133). */
+typedef struct {
+  float albedo[3];
+  float emission;
+  int32_t surface;
+} rtx_material;
+
+/* class Sphere, Obj.h:249-256 (centre, radius, material). */
+typedef struct {
+  float c[3];
+  float r;
+  rtx_material material;
+} rtx_sphere;
+
+/* The reference's compile-time constants as run-time fields:
+ * WIDTH/HEIGHT/EPS/NEE_EMISSION_THRESHOLD globals.h:3-8, MAX_BOUNCE_PROB
+ * Integrator.h:12, camera type and fov Raytracer.cpp:145-147, camera origin
+ * Camera.h:23, thin-lens defaults Camera.h:37-39, orthogonal stretch Camera.h:64-65. */
+typedef struct {
+  uint32_t width, height;
+  float fov;             /* degrees */
+  float cam_origin[3];   /* (0,1,3) in the reference */
+  float eps;             /* 1e-3 */
+  float nee_threshold;   /* 0.05 */
+  float rr_cap;          /* 0.99 */
+  int32_t sky;           /* 0: a miss adds nothing (the live reference, Integrator.h:113-116);
+                            1: a miss adds attenuation*skyEmission(d) (Integrator.h:114 un-commented) */
+  uint32_t max_bounces;  /* 0 = unbounded (the reference has no cap) */
+  int32_t camera;        /* 0 PerspectiveCamera, 1 ThinLensCamera, 2 OrthogonalCamera */
+  int32_t integrator;    /* 0 pathTrace (Integrator.h:98), 1 rayTraceNormals (Integrator.h:87) */
+  float focal_length, lens_radius; /* thin lens */
+  float stretch_x, stretch_y;      /* orthogonal */
+  int32_t device;        /* HIP device ordinal; -1 = the calling thread's current device */
+  uint32_t pool_paths;   /* capacity of the in-flight path pool; 0 = library default */
+} rtx_config;
+
+/* Scene geometry, borrowed for the duration of rtx_set_scene.
+ * triangles: num_triangles*9 floats (a,b,c); the primitive id of a triangle is
+ * its index here, which is the order Mesh::triangles has and EmbreeMesh copies
+ * (Obj.h:218-226).  material_index[i] selects materials[] for triangle i
+ * (Mesh::material_idxs, Obj.h:168). */
+typedef struct {
+  const float* triangles;
+  size_t num_triangles;
+  const uint32_t* material_index;
+  const rtx_material* materials;
+  size_t num_materials;
+  const rtx_sphere* spheres; /* Scene::spheres, Scene.h:37; may be NULL when num_spheres==0 */
+  size_t num_spheres;
+} rtx_scene;
+
+typedef struct {
+  uint64_t paths;        /* primary samples started */
+  uint64_t bounces;      /* closest-hit queries = iterations of the loop at Integrator.h:108 */
+  uint64_t nee_samples;  /* light samples taken (one isOccluded call each in the reference, Integrator.h:217) */
+  uint64_t shadow_rays;  /* shadow rays actually traced (light samples with a zero contribution are dropped) */
+  uint64_t iterations;   /* wavefront iterations (one intersect+shade round each) */
+  uint64_t launches;     /* kernel launches */
+  /* Filled only while profiling is on (rtx_set_profiling): device time per stage,
+   * measured with HIP events on the render stream, and launches timed. */
+  double ms_generate, ms_intersect, ms_shade, ms_shadow, ms_other;
+  uint64_t timed_launches_intersect, timed_launches_shade, timed_launches_shadow,
+      timed_launches_generate;
+  /* Units the timed launches processed (for bytes-per-launch figures). */
+  uint64_t timed_rays_intersect, timed_paths_shade, timed_rays_shadow, timed_paths_generate;
+} rtx_stats;
+
+typedef struct {
+  uint32_t num_nodes, num_triangles, num_lights, num_spheres, max_depth, stack_entries;
+  double build_ms;
+} rtx_scene_info;
+
+typedef struct rtx_ctx rtx_ctx;
+
+/* Message for the last failing call on this thread ("" if none). */
+const char* rtx_last_error(void);
+
+/* Replaces the construction of the globals camera/scene/gens (Raytracer.cpp:145,148,233):
+ * selects the GPU, allocates the path pool and queues. */
+int rtx_create(const rtx_config* cfg, rtx_ctx** out);
+void rtx_destroy(rtx_ctx* ctx);
+
+/* Replaces Scene::addMesh + Scene::commit (Scene.h:117-142): uploads the
+ * geometry, builds the BVH (in place of rtcCommitScene, Scene.h:123) and
+ * extracts the light list with the rule of Scene.h:129-141 (every triangle
+ * whose material emission exceeds nee_threshold, in triangle order).
+ * Synchronous. */
+int rtx_set_scene(rtx_ctx* ctx, const rtx_scene* scene);
+int rtx_get_scene_info(rtx_ctx* ctx, rtx_scene_info* out);
+
+/* Replaces one or more calls of render(img, pathTrace) (Raytracer.cpp:236-277,319):
+ * adds `spp` samples per pixel -- sample indices sample_base .. sample_base+spp-1 --
+ * of rows [row0,row1) into accum_dev, a device buffer of width*height*3 floats
+ * holding per-pixel SUMS (idx = px + py*width, the layout of Img::pixels,
+ * Raytracer.cpp:49,57-59).  row1 = 0 means all rows.  cam_offset is the global
+ * `pos` added to every ray origin (Raytracer.cpp:250); NULL = (0,0,0).
+ * The per-path random stream depends only on (pixel, sample index, seed), so
+ * disjoint sample ranges rendered on different GPUs add up to the same image as
+ * one GPU rendering the union.  Returns after the work has finished on `stream`
+ * (it polls the path queue's length while it drains). */
+int rtx_render(rtx_ctx* ctx, float* accum_dev, uint32_t spp, uint32_t sample_base, uint64_t seed,
+               const float cam_offset[3], uint32_t row0, uint32_t row1, void* stream);
+
+/* Replaces the division in Img::set/Img::update (Raytracer.cpp:70-81) and the
+ * hand-over of Img::pixels to the caller: rgb_out_host[i] = accum_dev[i] / total_spp,
+ * width*height*3 floats.  Synchronous. */
+int rtx_resolve(rtx_ctx* ctx, const float* accum_dev, uint32_t total_spp, float* rgb_out_host,
+                void* stream);
+
+/* Fixed-ray-set entry points (parity tests and tools).
+ * rays_host: n*6 floats (o, d); d is used as given (not normalised), as
+ * Scene::castRay does (Scene.h:144-189).  Outputs are host arrays of n elements
+ * (normal_out: n*3, may be NULL): kind 0 miss / 1 triangle / 2 sphere; prim =
+ * triangle index as passed to rtx_set_scene, or sphere index; t = hit distance
+ * (+inf on a miss).  Synchronous. */
+int rtx_trace_closest(rtx_ctx* ctx, const float* rays_host, size_t n, uint32_t* kind_out,
+                      uint32_t* prim_out, float* t_out, float* normal_out);
+/* Scene::isOccluded (Scene.h:191-225) for n segments: occluded_out[i] in {0,1}. */
+int rtx_trace_occluded(rtx_ctx* ctx, const float* rays_host, const float* distance_host, size_t n,
+                       uint8_t* occluded_out);
+
+/* Counters since rtx_create or the last rtx_reset_stats. */
+int rtx_get_stats(rtx_ctx* ctx, rtx_stats* out);
+int rtx_reset_stats(rtx_ctx* ctx);
+/* on != 0: time every kernel launch of rtx_render with HIP events on its stream
+ * (adds a few microseconds per launch). */
+int rtx_set_profiling(rtx_ctx* ctx, int on);
+
+/* Device-memory helpers for callers that do not link HIP themselves (a host
+ * front end built with g++).  rtx_accum_clear replaces Img::clear
+ * (Raytracer.cpp:61-68). */
+int rtx_accum_alloc(rtx_ctx* ctx, float** accum_dev_out);
+int rtx_accum_free(rtx_ctx* ctx, float* accum_dev);
+int rtx_accum_clear(rtx_ctx* ctx, float* accum_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

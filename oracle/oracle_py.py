@@ -1,0 +1,268 @@
+"""ctypes binding of the CPU oracle (oracle/librt_oracle.so) and of the reference's
+own Pcg build (oracle/_ref/libref_pcg.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product package (raytracer_amd) never imports it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_oracle.so")
+REF_PCG_PATH = os.path.join(_HERE, "_ref", "libref_pcg.so")
+
+
+class OMaterial(C.Structure):
+    _fields_ = [("albedo", C.c_float * 3), ("emission", C.c_float), ("surface", C.c_int32)]
+
+
+class OSphere(C.Structure):
+    _fields_ = [("c", C.c_float * 3), ("r", C.c_float), ("material", OMaterial)]
+
+
+class OConfig(C.Structure):
+    _fields_ = [
+        ("width", C.c_uint32), ("height", C.c_uint32), ("fov", C.c_float),
+        ("cam_origin", C.c_float * 3), ("eps", C.c_float), ("nee_threshold", C.c_float),
+        ("rr_cap", C.c_float), ("sky", C.c_int32), ("max_bounces", C.c_uint32),
+        ("camera", C.c_int32), ("integrator", C.c_int32),
+        ("focal_length", C.c_float), ("lens_radius", C.c_float),
+        ("stretch_x", C.c_float), ("stretch_y", C.c_float),
+    ]
+
+
+class OStats(C.Structure):
+    _fields_ = [("paths", C.c_uint64), ("bounces", C.c_uint64), ("nee_samples", C.c_uint64),
+                ("nan_paths", C.c_uint64)]
+
+
+_lib = None
+
+
+def build(force: bool = False):
+    """Compiles the oracle with its Makefile (g++); the reference Pcg too when the
+    reference checkout exists."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "-s"], stdout=subprocess.DEVNULL)
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(LIB_PATH)
+        vp, u32, u64, sz, i = C.c_void_p, C.c_uint32, C.c_uint64, C.c_size_t, C.c_int
+        L.orc_pcg_hash.restype = u32
+        L.orc_pcg_hash.argtypes = [u32]
+        L.orc_pcg_rand.argtypes = [C.POINTER(u32), vp, sz]
+        L.orc_pcg_uniform.argtypes = [C.POINTER(u32), vp, sz]
+        L.orc_path_seed.restype = u32
+        L.orc_path_seed.argtypes = [u32, u32, u64]
+        L.orc_rot_matrix_vectors.argtypes = [vp, vp, vp]
+        L.orc_mat_vec.argtypes = [vp, vp, vp]
+        L.orc_cosine_sample_hemisphere.argtypes = [C.POINTER(u32), vp]
+        L.orc_schlick.restype = C.c_float
+        L.orc_schlick.argtypes = [C.c_float, C.c_float]
+        L.orc_sky_emission.argtypes = [vp, vp]
+        L.orc_triangle_intersect.restype = C.c_float
+        L.orc_triangle_intersect.argtypes = [vp] * 5
+        L.orc_sphere_intersect.restype = C.c_float
+        L.orc_sphere_intersect.argtypes = [vp, C.c_float, vp, vp]
+        L.orc_triangle_sample_point.restype = C.c_float
+        L.orc_triangle_sample_point.argtypes = [vp, vp, vp, C.POINTER(u32), vp, vp]
+        L.orc_camera_ray.argtypes = [C.POINTER(OConfig), C.c_float, C.c_float, C.POINTER(u32), vp, vp]
+        L.orc_img_update.argtypes = [vp, u32, vp]
+        L.orc_scene_create.restype = vp
+        L.orc_scene_create.argtypes = [vp, sz, vp, vp, sz, vp, sz, C.POINTER(OConfig)]
+        L.orc_scene_destroy.argtypes = [vp]
+        L.orc_scene_destroy.restype = None
+        L.orc_scene_num_lights.restype = sz
+        L.orc_scene_num_lights.argtypes = [vp]
+        L.orc_trace_closest.argtypes = [vp, vp, sz, i, vp, vp, vp, vp]
+        L.orc_trace_occluded.argtypes = [vp, vp, vp, sz, i, vp]
+        L.orc_path_trace.argtypes = [vp, u32, u32, u64, vp, i, vp, C.POINTER(u32)]
+        L.orc_render.argtypes = [vp, u32, u32, u64, vp, i, i, u32, u32, vp, C.POINTER(OStats)]
+        _lib = L
+    return _lib
+
+
+def ref_pcg() -> Optional[C.CDLL]:
+    """The reference's own Sampler.h compiled unchanged (None if it was never built)."""
+    if not os.path.exists(REF_PCG_PATH):
+        return None
+    L = C.CDLL(REF_PCG_PATH)
+    L.ref_pcg_hash.restype = C.c_uint32
+    L.ref_pcg_hash.argtypes = [C.c_uint32]
+    L.ref_pcg_rand.argtypes = [C.POINTER(C.c_uint32), C.c_void_p, C.c_size_t]
+    L.ref_pcg_uniform.argtypes = [C.POINTER(C.c_uint32), C.c_void_p, C.c_size_t]
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f3(v):
+    return np.ascontiguousarray(v, np.float32).reshape(3)
+
+
+def config_from(cfg) -> OConfig:
+    """cfg: any object with the fields of raytracer_amd.capi.Config."""
+    o = OConfig()
+    o.width, o.height, o.fov = cfg.width, cfg.height, cfg.fov
+    o.cam_origin = (C.c_float * 3)(*cfg.cam_origin)
+    o.eps, o.nee_threshold, o.rr_cap = cfg.eps, cfg.nee_threshold, cfg.rr_cap
+    o.sky, o.max_bounces, o.camera, o.integrator = cfg.sky, cfg.max_bounces, cfg.camera, cfg.integrator
+    o.focal_length, o.lens_radius = cfg.focal_length, cfg.lens_radius
+    o.stretch_x, o.stretch_y = cfg.stretch_x, cfg.stretch_y
+    return o
+
+
+def pcg_rand(seed: int, n: int, which=None):
+    L = which or lib()
+    st = C.c_uint32(seed)
+    out = np.empty(n, np.uint32)
+    (L.ref_pcg_rand if which is not None else L.orc_pcg_rand)(C.byref(st), _p(out), n)
+    return out, st.value
+
+
+def pcg_uniform(seed: int, n: int, which=None):
+    L = which or lib()
+    st = C.c_uint32(seed)
+    out = np.empty(n, np.float32)
+    (L.ref_pcg_uniform if which is not None else L.orc_pcg_uniform)(C.byref(st), _p(out), n)
+    return out, st.value
+
+
+def rot_matrix_vectors(a, b) -> np.ndarray:
+    m = np.empty(9, np.float32)
+    lib().orc_rot_matrix_vectors(_p(_f3(a)), _p(_f3(b)), _p(m))
+    return m.reshape(3, 3)
+
+
+def mat_vec(m, v) -> np.ndarray:
+    out = np.empty(3, np.float32)
+    lib().orc_mat_vec(_p(np.ascontiguousarray(m, np.float32).reshape(9)), _p(_f3(v)), _p(out))
+    return out
+
+
+def cosine_sample_hemisphere(state: int):
+    st = C.c_uint32(state)
+    out = np.empty(3, np.float32)
+    lib().orc_cosine_sample_hemisphere(C.byref(st), _p(out))
+    return out, st.value
+
+
+def sky_emission(d) -> np.ndarray:
+    out = np.empty(3, np.float32)
+    lib().orc_sky_emission(_p(_f3(d)), _p(out))
+    return out
+
+
+def triangle_intersect(a, b, c, o, d) -> float:
+    return float(lib().orc_triangle_intersect(_p(_f3(a)), _p(_f3(b)), _p(_f3(c)), _p(_f3(o)), _p(_f3(d))))
+
+
+def sphere_intersect(c, r, o, d) -> float:
+    return float(lib().orc_sphere_intersect(_p(_f3(c)), r, _p(_f3(o)), _p(_f3(d))))
+
+
+def triangle_sample_point(a, b, c, state: int):
+    st = C.c_uint32(state)
+    p = np.empty(3, np.float32)
+    n = np.empty(3, np.float32)
+    rcp = lib().orc_triangle_sample_point(_p(_f3(a)), _p(_f3(b)), _p(_f3(c)), C.byref(st), _p(p), _p(n))
+    return p, n, float(rcp), st.value
+
+
+def camera_ray(cfg, px: float, py: float, state: int = 0):
+    oc = config_from(cfg)
+    st = C.c_uint32(state)
+    o = np.empty(3, np.float32)
+    d = np.empty(3, np.float32)
+    lib().orc_camera_ray(C.byref(oc), px, py, C.byref(st), _p(o), _p(d))
+    return o, d, st.value
+
+
+def img_update(pixel, sample_count: int, color) -> np.ndarray:
+    px = _f3(pixel).copy()
+    lib().orc_img_update(_p(px), sample_count, _p(_f3(color)))
+    return px
+
+
+class OracleScene:
+    """Scene + config for the oracle; `scene` is a raytracer_amd.capi.SceneData-like
+    object (triangles (n,9) f32, material_index u32, materials/spheres structured arrays
+    with the 20/36-byte layouts)."""
+
+    def __init__(self, scene, cfg):
+        self.cfg = cfg
+        self._oc = config_from(cfg)
+        self._keep = (scene.triangles, scene.material_index, scene.materials, scene.spheres)
+        L = lib()
+        self._h = L.orc_scene_create(_p(scene.triangles), scene.triangles.shape[0],
+                                     _p(scene.material_index), _p(scene.materials),
+                                     scene.materials.shape[0],
+                                     _p(scene.spheres) if len(scene.spheres) else None,
+                                     len(scene.spheres), C.byref(self._oc))
+        if not self._h:
+            raise ValueError("orc_scene_create failed (material index out of range?)")
+
+    def close(self):
+        if self._h:
+            lib().orc_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def num_lights(self) -> int:
+        return int(lib().orc_scene_num_lights(self._h))
+
+    def trace_closest(self, rays, use_bvh: bool = False, want_normal: bool = True):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        n = rays.shape[0]
+        kind = np.empty(n, np.uint32)
+        prim = np.empty(n, np.uint32)
+        t = np.empty(n, np.float32)
+        nrm = np.empty((n, 3), np.float32) if want_normal else None
+        lib().orc_trace_closest(self._h, _p(rays), n, int(use_bvh), _p(kind), _p(prim), _p(t), _p(nrm))
+        return kind, prim, t, nrm
+
+    def trace_occluded(self, rays, dist, use_bvh: bool = False):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        dist = np.ascontiguousarray(dist, np.float32).reshape(-1)
+        out = np.empty(rays.shape[0], np.uint8)
+        lib().orc_trace_occluded(self._h, _p(rays), _p(dist), rays.shape[0], int(use_bvh), _p(out))
+        return out
+
+    def path_trace(self, pixel_index: int, sample_index: int, seed: int = 0x5EED,
+                   cam_offset: Optional[Sequence[float]] = None, use_bvh: bool = True):
+        col = np.empty(3, np.float32)
+        b = C.c_uint32()
+        off = _f3(cam_offset) if cam_offset is not None else None
+        lib().orc_path_trace(self._h, pixel_index, sample_index, seed, _p(off), int(use_bvh), _p(col),
+                             C.byref(b))
+        return col, b.value
+
+    def render(self, spp: int, sample_base: int = 0, seed: int = 0x5EED,
+               cam_offset: Optional[Sequence[float]] = None, use_bvh: bool = True, nthreads: int = 0,
+               row0: int = 0, row1: int = 0, accum: Optional[np.ndarray] = None):
+        """Returns (sum image (H,W,3) float32, OStats)."""
+        if accum is None:
+            accum = np.zeros((self.cfg.height, self.cfg.width, 3), np.float32)
+        st = OStats()
+        off = _f3(cam_offset) if cam_offset is not None else None
+        lib().orc_render(self._h, spp, sample_base, seed, _p(off), int(use_bvh), nthreads, row0, row1,
+                         _p(accum), C.byref(st))
+        return accum, st

@@ -1,0 +1,302 @@
+"""ctypes binding of the C ABI in include/rtx_capi.h.
+
+This is the Python-side host layer used by the tests and bench.py; the C++ host
+layer for a Raytracer.cpp-shaped driver is raytracer_amd/host/.  Nothing here
+computes: every method forwards to librtx_hip.so and raises RtxError with the
+library's message on a non-zero status.  There is no fallback of any kind: a
+missing library or GPU is an error.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librtx_hip.so")
+
+
+class RtxError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"rtx status {status}: {message}")
+        self.status = status
+
+
+# ---- struct mirrors (same layouts as include/rtx_capi.h) ---------------------
+class Material(C.Structure):
+    _fields_ = [("albedo", C.c_float * 3), ("emission", C.c_float), ("surface", C.c_int32)]
+
+
+class Sphere(C.Structure):
+    _fields_ = [("c", C.c_float * 3), ("r", C.c_float), ("material", Material)]
+
+
+class CConfig(C.Structure):
+    _fields_ = [
+        ("width", C.c_uint32), ("height", C.c_uint32), ("fov", C.c_float),
+        ("cam_origin", C.c_float * 3), ("eps", C.c_float), ("nee_threshold", C.c_float),
+        ("rr_cap", C.c_float), ("sky", C.c_int32), ("max_bounces", C.c_uint32),
+        ("camera", C.c_int32), ("integrator", C.c_int32),
+        ("focal_length", C.c_float), ("lens_radius", C.c_float),
+        ("stretch_x", C.c_float), ("stretch_y", C.c_float),
+        ("device", C.c_int32), ("pool_paths", C.c_uint32),
+    ]
+
+
+class CScene(C.Structure):
+    _fields_ = [
+        ("triangles", C.POINTER(C.c_float)), ("num_triangles", C.c_size_t),
+        ("material_index", C.POINTER(C.c_uint32)),
+        ("materials", C.POINTER(Material)), ("num_materials", C.c_size_t),
+        ("spheres", C.POINTER(Sphere)), ("num_spheres", C.c_size_t),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("paths", C.c_uint64), ("bounces", C.c_uint64), ("nee_samples", C.c_uint64),
+        ("shadow_rays", C.c_uint64), ("iterations", C.c_uint64), ("launches", C.c_uint64),
+        ("ms_generate", C.c_double), ("ms_intersect", C.c_double), ("ms_shade", C.c_double),
+        ("ms_shadow", C.c_double), ("ms_other", C.c_double),
+        ("timed_launches_intersect", C.c_uint64), ("timed_launches_shade", C.c_uint64),
+        ("timed_launches_shadow", C.c_uint64), ("timed_launches_generate", C.c_uint64),
+        ("timed_rays_intersect", C.c_uint64), ("timed_paths_shade", C.c_uint64),
+        ("timed_rays_shadow", C.c_uint64), ("timed_paths_generate", C.c_uint64),
+    ]
+
+    def as_dict(self) -> dict:
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class SceneInfo(C.Structure):
+    _fields_ = [
+        ("num_nodes", C.c_uint32), ("num_triangles", C.c_uint32), ("num_lights", C.c_uint32),
+        ("num_spheres", C.c_uint32), ("max_depth", C.c_uint32), ("stack_entries", C.c_uint32),
+        ("build_ms", C.c_double),
+    ]
+
+
+# Every symbol include/rtx_capi.h declares (tests check the library exports them all).
+SYMBOLS = [
+    "rtx_last_error", "rtx_create", "rtx_destroy", "rtx_set_scene", "rtx_get_scene_info",
+    "rtx_render", "rtx_resolve", "rtx_trace_closest", "rtx_trace_occluded", "rtx_get_stats",
+    "rtx_reset_stats", "rtx_set_profiling", "rtx_accum_alloc", "rtx_accum_free", "rtx_accum_clear",
+]
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """Loads librtx_hip.so (built in-tree by raytracer_amd/csrc/Makefile)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ImportError(
+            f"{p} not found: build it with `make -C raytracer_amd/csrc` "
+            "(there is no CPU fallback for the renderer)")
+    lib = C.CDLL(p)
+    vp, u32, u64, sz = C.c_void_p, C.c_uint32, C.c_uint64, C.c_size_t
+    fp = C.POINTER(C.c_float)
+    lib.rtx_last_error.restype = C.c_char_p
+    lib.rtx_last_error.argtypes = []
+    lib.rtx_create.argtypes = [C.POINTER(CConfig), C.POINTER(vp)]
+    lib.rtx_destroy.argtypes = [vp]
+    lib.rtx_destroy.restype = None
+    lib.rtx_set_scene.argtypes = [vp, C.POINTER(CScene)]
+    lib.rtx_get_scene_info.argtypes = [vp, C.POINTER(SceneInfo)]
+    lib.rtx_render.argtypes = [vp, vp, u32, u32, u64, fp, u32, u32, vp]
+    lib.rtx_resolve.argtypes = [vp, vp, u32, vp, vp]
+    lib.rtx_trace_closest.argtypes = [vp, vp, sz, vp, vp, vp, vp]
+    lib.rtx_trace_occluded.argtypes = [vp, vp, vp, sz, vp]
+    lib.rtx_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    lib.rtx_reset_stats.argtypes = [vp]
+    lib.rtx_set_profiling.argtypes = [vp, C.c_int]
+    lib.rtx_accum_alloc.argtypes = [vp, C.POINTER(vp)]
+    lib.rtx_accum_free.argtypes = [vp, vp]
+    lib.rtx_accum_clear.argtypes = [vp, vp, vp]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+@dataclass
+class Config:
+    """Run-time form of the reference's compile-time constants (see rtx_config)."""
+    width: int = 800
+    height: int = 800
+    fov: float = 50.0
+    cam_origin: Sequence[float] = (0.0, 1.0, 3.0)
+    eps: float = 1.0e-3
+    nee_threshold: float = 0.05
+    rr_cap: float = 0.99
+    sky: int = 0
+    max_bounces: int = 0
+    camera: int = 0
+    integrator: int = 0
+    focal_length: float = 2.4
+    lens_radius: float = 0.09
+    stretch_x: float = 1.2
+    stretch_y: float = 1.2
+    device: int = -1
+    pool_paths: int = 0
+
+    def to_c(self) -> CConfig:
+        c = CConfig()
+        c.width, c.height, c.fov = self.width, self.height, self.fov
+        c.cam_origin = (C.c_float * 3)(*self.cam_origin)
+        c.eps, c.nee_threshold, c.rr_cap = self.eps, self.nee_threshold, self.rr_cap
+        c.sky, c.max_bounces, c.camera, c.integrator = self.sky, self.max_bounces, self.camera, self.integrator
+        c.focal_length, c.lens_radius = self.focal_length, self.lens_radius
+        c.stretch_x, c.stretch_y = self.stretch_x, self.stretch_y
+        c.device, c.pool_paths = self.device, self.pool_paths
+        return c
+
+
+MATERIAL_DTYPE = np.dtype([("albedo", "<f4", 3), ("emission", "<f4"), ("surface", "<i4")])
+SPHERE_DTYPE = np.dtype([("c", "<f4", 3), ("r", "<f4"), ("material", MATERIAL_DTYPE)])
+assert MATERIAL_DTYPE.itemsize == C.sizeof(Material) == 20
+assert SPHERE_DTYPE.itemsize == C.sizeof(Sphere) == 36
+
+
+@dataclass
+class SceneData:
+    """Flat scene arrays in the layout rtx_set_scene takes."""
+    triangles: np.ndarray            # (n, 9) float32: a, b, c
+    material_index: np.ndarray       # (n,) uint32
+    materials: np.ndarray            # (m,) MATERIAL_DTYPE
+    spheres: np.ndarray = field(default_factory=lambda: np.zeros(0, SPHERE_DTYPE))
+    name: str = ""
+
+    def __post_init__(self):
+        self.triangles = np.ascontiguousarray(self.triangles, dtype=np.float32).reshape(-1, 9)
+        self.material_index = np.ascontiguousarray(self.material_index, dtype=np.uint32)
+        self.materials = np.ascontiguousarray(self.materials, dtype=MATERIAL_DTYPE)
+        self.spheres = np.ascontiguousarray(self.spheres, dtype=SPHERE_DTYPE)
+        assert self.triangles.shape[0] == self.material_index.shape[0]
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _dev_ptr(buf) -> int:
+    """Address of a device buffer: an int, or anything with data_ptr() (a torch tensor)."""
+    if hasattr(buf, "data_ptr"):
+        return int(buf.data_ptr())
+    return int(buf)
+
+
+class Renderer:
+    """One rtx_ctx: the replacement for the reference's scene/camera/gens globals
+    and its render(img, pathTrace) call (Raytracer.cpp:145-148,233,236-286)."""
+
+    def __init__(self, cfg: Config, lib: Optional[C.CDLL] = None):
+        self.lib = lib or load_library()
+        self.cfg = cfg
+        self._ctx = C.c_void_p()
+        cc = cfg.to_c()
+        self._check(self.lib.rtx_create(C.byref(cc), C.byref(self._ctx)))
+        self._own_accum = []
+
+    def _check(self, status: int):
+        if status != 0:
+            raise RtxError(status, self.lib.rtx_last_error().decode())
+
+    def close(self):
+        if self._ctx:
+            for p in self._own_accum:
+                self.lib.rtx_accum_free(self._ctx, p)
+            self._own_accum = []
+            self.lib.rtx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- scene ---------------------------------------------------------------
+    def set_scene(self, s: SceneData) -> SceneInfo:
+        cs = CScene()
+        cs.triangles = s.triangles.ctypes.data_as(C.POINTER(C.c_float))
+        cs.num_triangles = s.triangles.shape[0]
+        cs.material_index = s.material_index.ctypes.data_as(C.POINTER(C.c_uint32))
+        cs.materials = s.materials.ctypes.data_as(C.POINTER(Material))
+        cs.num_materials = s.materials.shape[0]
+        cs.spheres = s.spheres.ctypes.data_as(C.POINTER(Sphere)) if len(s.spheres) else None
+        cs.num_spheres = len(s.spheres)
+        self._check(self.lib.rtx_set_scene(self._ctx, C.byref(cs)))
+        return self.scene_info()
+
+    def scene_info(self) -> SceneInfo:
+        info = SceneInfo()
+        self._check(self.lib.rtx_get_scene_info(self._ctx, C.byref(info)))
+        return info
+
+    # -- accumulation buffers --------------------------------------------------
+    def accum_alloc(self) -> int:
+        p = C.c_void_p()
+        self._check(self.lib.rtx_accum_alloc(self._ctx, C.byref(p)))
+        self._own_accum.append(p.value)
+        return p.value
+
+    def accum_clear(self, accum, stream: int = 0):
+        self._check(self.lib.rtx_accum_clear(self._ctx, _dev_ptr(accum), stream))
+
+    # -- rendering ---------------------------------------------------------------
+    def render(self, accum, spp: int, sample_base: int = 0, seed: int = 0x5EED,
+               cam_offset: Optional[Sequence[float]] = None, row0: int = 0, row1: int = 0,
+               stream: int = 0):
+        off = (C.c_float * 3)(*cam_offset) if cam_offset is not None else None
+        self._check(self.lib.rtx_render(self._ctx, _dev_ptr(accum), spp, sample_base, seed, off,
+                                        row0, row1, stream))
+
+    def resolve(self, accum, total_spp: int, stream: int = 0) -> np.ndarray:
+        out = np.empty((self.cfg.height, self.cfg.width, 3), np.float32)
+        self._check(self.lib.rtx_resolve(self._ctx, _dev_ptr(accum), total_spp, _ptr(out), stream))
+        return out
+
+    # -- fixed ray sets ------------------------------------------------------------
+    def trace_closest(self, rays: np.ndarray, want_normal: bool = True):
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        n = rays.shape[0]
+        kind = np.empty(n, np.uint32)
+        prim = np.empty(n, np.uint32)
+        t = np.empty(n, np.float32)
+        nrm = np.empty((n, 3), np.float32) if want_normal else None
+        self._check(self.lib.rtx_trace_closest(self._ctx, _ptr(rays), n, _ptr(kind), _ptr(prim),
+                                               _ptr(t), _ptr(nrm)))
+        return kind, prim, t, nrm
+
+    def trace_occluded(self, rays: np.ndarray, dist: np.ndarray) -> np.ndarray:
+        rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+        dist = np.ascontiguousarray(dist, np.float32).reshape(-1)
+        assert dist.shape[0] == rays.shape[0]
+        out = np.empty(rays.shape[0], np.uint8)
+        self._check(self.lib.rtx_trace_occluded(self._ctx, _ptr(rays), _ptr(dist), rays.shape[0],
+                                                _ptr(out)))
+        return out
+
+    # -- statistics ------------------------------------------------------------------
+    def stats(self) -> Stats:
+        s = Stats()
+        self._check(self.lib.rtx_get_stats(self._ctx, C.byref(s)))
+        return s
+
+    def reset_stats(self):
+        self._check(self.lib.rtx_reset_stats(self._ctx))
+
+    def set_profiling(self, on: bool):
+        self._check(self.lib.rtx_set_profiling(self._ctx, 1 if on else 0))

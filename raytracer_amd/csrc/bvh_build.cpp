@@ -1,0 +1,262 @@
+// bvh_build.cpp -- binned-SAH BVH2 builder and flattener (host code).
+// See bvh_build.h for the node format and what it replaces in the reference.
+#include "bvh_build.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace rtx {
+namespace {
+
+constexpr int kBins = 16;
+constexpr uint32_t kMaxLeaf = 4;       // a node with more triangles is always split
+constexpr uint32_t kMaxSahDepth = 40;  // below this depth, fall back to median splits
+
+struct Box {
+  float lo[3], hi[3];
+  void reset() {
+    for (int k = 0; k < 3; k++) {
+      lo[k] = std::numeric_limits<float>::infinity();
+      hi[k] = -std::numeric_limits<float>::infinity();
+    }
+  }
+  void grow(const Box& b) {
+    for (int k = 0; k < 3; k++) {
+      lo[k] = std::min(lo[k], b.lo[k]);
+      hi[k] = std::max(hi[k], b.hi[k]);
+    }
+  }
+  void grow_point(const float* p) {
+    for (int k = 0; k < 3; k++) {
+      lo[k] = std::min(lo[k], p[k]);
+      hi[k] = std::max(hi[k], p[k]);
+    }
+  }
+  float half_area() const {
+    float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    if (!(dx >= 0.f) || !(dy >= 0.f) || !(dz >= 0.f)) return 0.f;
+    return dx * dy + dy * dz + dz * dx;
+  }
+};
+
+struct TmpNode {
+  Box box;
+  int32_t left = -1, right = -1;  // inner when left >= 0
+  uint32_t first = 0, count = 0;
+};
+
+struct Builder {
+  const std::vector<Box>& tb;      // per-triangle bounds
+  const std::vector<float>& cent;  // per-triangle centroid (3 floats)
+  std::vector<uint32_t>& order;
+  std::vector<TmpNode> nodes;
+
+  Builder(const std::vector<Box>& tb_, const std::vector<float>& c_, std::vector<uint32_t>& o_)
+      : tb(tb_), cent(c_), order(o_) {}
+
+  int32_t build(uint32_t first, uint32_t count, uint32_t depth) {
+    int32_t id = (int32_t)nodes.size();
+    nodes.emplace_back();
+    Box box, cbox;
+    box.reset();
+    cbox.reset();
+    for (uint32_t i = first; i < first + count; i++) {
+      box.grow(tb[order[i]]);
+      cbox.grow_point(&cent[3 * (size_t)order[i]]);
+    }
+    nodes[id].box = box;
+    nodes[id].first = first;
+    nodes[id].count = count;
+    if (count <= kMaxLeaf) return id;
+
+    uint32_t mid = 0;
+    bool have_split = false;
+    if (depth < kMaxSahDepth) {
+      // Binned SAH over the three axes of the centroid box.
+      float best_cost = std::numeric_limits<float>::infinity();
+      int best_axis = -1, best_bin = -1;
+      for (int axis = 0; axis < 3; axis++) {
+        float ext = cbox.hi[axis] - cbox.lo[axis];
+        if (!(ext > 0.f)) continue;
+        float scale = (float)kBins / ext;
+        Box bb[kBins];
+        uint32_t bc[kBins];
+        for (int b = 0; b < kBins; b++) {
+          bb[b].reset();
+          bc[b] = 0;
+        }
+        for (uint32_t i = first; i < first + count; i++) {
+          uint32_t p = order[i];
+          int b = (int)((cent[3 * (size_t)p + axis] - cbox.lo[axis]) * scale);
+          b = std::min(std::max(b, 0), kBins - 1);
+          bb[b].grow(tb[p]);
+          bc[b]++;
+        }
+        float right_area[kBins];
+        uint32_t right_cnt[kBins];
+        Box acc;
+        acc.reset();
+        uint32_t n = 0;
+        for (int b = kBins - 1; b > 0; b--) {
+          acc.grow(bb[b]);
+          n += bc[b];
+          right_area[b] = acc.half_area();
+          right_cnt[b] = n;
+        }
+        acc.reset();
+        n = 0;
+        for (int b = 0; b < kBins - 1; b++) {
+          acc.grow(bb[b]);
+          n += bc[b];
+          if (n == 0 || right_cnt[b + 1] == 0) continue;
+          float cost = acc.half_area() * (float)n + right_area[b + 1] * (float)right_cnt[b + 1];
+          if (cost < best_cost) {
+            best_cost = cost;
+            best_axis = axis;
+            best_bin = b;
+          }
+        }
+      }
+      if (best_axis >= 0) {
+        float ext = cbox.hi[best_axis] - cbox.lo[best_axis];
+        float scale = (float)kBins / ext;
+        float lo = cbox.lo[best_axis];
+        auto it = std::partition(order.begin() + first, order.begin() + first + count,
+                                 [&](uint32_t p) {
+                                   int b = (int)((cent[3 * (size_t)p + best_axis] - lo) * scale);
+                                   b = std::min(std::max(b, 0), kBins - 1);
+                                   return b <= best_bin;
+                                 });
+        mid = (uint32_t)(it - order.begin());
+        have_split = mid > first && mid < first + count;
+      }
+    }
+    if (!have_split) {
+      // Median split on the widest centroid axis (ties and degenerate inputs by index).
+      int axis = 0;
+      for (int k = 1; k < 3; k++)
+        if (cbox.hi[k] - cbox.lo[k] > cbox.hi[axis] - cbox.lo[axis]) axis = k;
+      mid = first + count / 2;
+      std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
+                       [&](uint32_t p, uint32_t q) {
+                         float cp = cent[3 * (size_t)p + axis], cq = cent[3 * (size_t)q + axis];
+                         return cp < cq || (cp == cq && p < q);
+                       });
+    }
+    int32_t l = build(first, mid - first, depth + 1);
+    int32_t r = build(mid, first + count - mid, depth + 1);
+    nodes[id].left = l;
+    nodes[id].right = r;
+    return id;
+  }
+};
+
+inline float as_float(int32_t v) {
+  float f;
+  std::memcpy(&f, &v, 4);
+  return f;
+}
+
+struct Flattener {
+  const std::vector<TmpNode>& tmp;
+  std::vector<float>& out;
+  uint32_t max_depth = 0;
+
+  static void padded(const Box& b, float lo[3], float hi[3]) {
+    float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    float diag = std::sqrt(dx * dx + dy * dy + dz * dz);
+    for (int k = 0; k < 3; k++) {
+      float pad = 2e-6f * std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k])) + 1e-5f * diag + 1e-30f;
+      lo[k] = b.lo[k] - pad;
+      hi[k] = b.hi[k] + pad;
+    }
+  }
+  int32_t child_ref(int32_t t, uint32_t depth) {
+    const TmpNode& n = tmp[t];
+    if (n.left < 0) {
+      uint32_t v = (n.first << 3) | (n.count - 1);
+      return ~(int32_t)v;
+    }
+    return emit_inner(t, depth);
+  }
+  // Emits tmp node t (an inner node) and its subtree; returns its flat index.
+  int32_t emit_inner(int32_t t, uint32_t depth) {
+    int32_t idx = (int32_t)(out.size() / 16);
+    out.resize(out.size() + 16, 0.f);
+    max_depth = std::max(max_depth, depth + 1);
+    const TmpNode& n = tmp[t];
+    float l0[3], h0[3], l1[3], h1[3];
+    padded(tmp[n.left].box, l0, h0);
+    padded(tmp[n.right].box, l1, h1);
+    int32_t c0 = child_ref(n.left, depth + 1);
+    int32_t c1 = child_ref(n.right, depth + 1);
+    float* q = &out[(size_t)idx * 16];
+    q[0] = l0[0]; q[1] = h0[0]; q[2] = l0[1]; q[3] = h0[1];
+    q[4] = l1[0]; q[5] = h1[0]; q[6] = l1[1]; q[7] = h1[1];
+    q[8] = l0[2]; q[9] = h0[2]; q[10] = l1[2]; q[11] = h1[2];
+    q[12] = as_float(c0);
+    q[13] = as_float(c1);
+    return idx;
+  }
+};
+
+}  // namespace
+
+void build_bvh(const float* tris, size_t ntri, FlatBvh& out) {
+  out.nodes.clear();
+  out.order.clear();
+  out.max_depth = 0;
+  if (ntri == 0) return;  // no mesh: the kernels skip the traversal when there are no nodes
+  std::vector<Box> tb(ntri);
+  std::vector<float> cent(3 * ntri);
+  for (size_t i = 0; i < ntri; i++) {
+    tb[i].reset();
+    tb[i].grow_point(tris + 9 * i);
+    tb[i].grow_point(tris + 9 * i + 3);
+    tb[i].grow_point(tris + 9 * i + 6);
+    for (int k = 0; k < 3; k++) cent[3 * i + k] = 0.5f * tb[i].lo[k] + 0.5f * tb[i].hi[k];
+  }
+  out.order.resize(ntri);
+  for (size_t i = 0; i < ntri; i++) out.order[i] = (uint32_t)i;
+  Builder b(tb, cent, out.order);
+  b.nodes.reserve(ntri);
+  int32_t root = b.build(0, (uint32_t)ntri, 0);
+
+  // Leaves keep their triangles in ascending primitive order (helps the
+  // lowest-index tie-break find the winner first).
+  for (const TmpNode& n : b.nodes)
+    if (n.left < 0) std::sort(out.order.begin() + n.first, out.order.begin() + n.first + n.count);
+
+  Flattener f{b.nodes, out.nodes};
+  out.nodes.reserve(16 * ntri / 2 + 16);
+  if (b.nodes[root].left < 0) {
+    // The whole mesh fits one leaf.  The root is always an inner node, so cut
+    // the leaf in two (a single triangle is referenced by both children; testing
+    // it twice cannot change the result).
+    uint32_t cnt = b.nodes[root].count, h = cnt > 1 ? cnt / 2 : 1;
+    uint32_t first1 = cnt > 1 ? h : 0, cnt1 = cnt > 1 ? cnt - h : 1;
+    Box b0, b1;
+    b0.reset();
+    b1.reset();
+    for (uint32_t i = 0; i < h; i++) b0.grow(tb[out.order[i]]);
+    for (uint32_t i = first1; i < first1 + cnt1; i++) b1.grow(tb[out.order[i]]);
+    float l0[3], h0[3], l1[3], h1[3];
+    Flattener::padded(b0, l0, h0);
+    Flattener::padded(b1, l1, h1);
+    out.nodes.assign(16, 0.f);
+    float* q = out.nodes.data();
+    q[0] = l0[0]; q[1] = h0[0]; q[2] = l0[1]; q[3] = h0[1];
+    q[4] = l1[0]; q[5] = h1[0]; q[6] = l1[1]; q[7] = h1[1];
+    q[8] = l0[2]; q[9] = h0[2]; q[10] = l1[2]; q[11] = h1[2];
+    q[12] = as_float(~(int32_t)((0u << 3) | (h - 1)));
+    q[13] = as_float(~(int32_t)((first1 << 3) | (cnt1 - 1)));
+    out.max_depth = 1;
+    return;
+  }
+  f.emit_inner(root, 0);
+  out.max_depth = f.max_depth;
+}
+
+}  // namespace rtx

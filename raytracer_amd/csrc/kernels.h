@@ -1,0 +1,751 @@
+// kernels.h -- the wavefront path tracer's device code (gfx950, wave64).
+//
+// One kernel per stage over SoA queues in HBM, as the reference's own TODO asks
+// ("small kernels over a singular megakernel", "all the attributes of a certain
+// type are arrays", reference README.md:40-42):
+//
+//   k_generate   primary rays for new samples         (Raytracer.cpp:246-250, Camera.h)
+//   k_intersect  closest hit: BVH2 + spheres          (Scene.h:144-189)
+//   k_shade      emission/MIS, Russian roulette, BRDF sampling, NEE set-up,
+//                compaction of the survivors           (Integrator.h:98-291)
+//   k_shadow     any-hit for the NEE segments          (Scene.h:191-225)
+//   k_advance    queue bookkeeping (one thread)
+//
+// Path state lives in five SoA arrays (64 bytes per path) that every kernel
+// reads and writes with 8- or 16-byte coalesced accesses:
+//   r0 float4 (o.x, o.y, o.z, d.x)     r1 float2 (d.y, d.z)
+//   s0 float4 (attenuation.rgb, mis_brdf_pdf)
+//   s1 float4 (colour.rgb, nee_pdf)    s2 uint2  (pixel index, rng state)
+// There are two such queues; k_shade reads one and appends the surviving paths
+// to the other (ballot + mbcnt prefix, one atomic per wave).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_math.h"
+
+namespace rtx {
+
+constexpr uint32_t kMiss = 0xffffffffu;
+constexpr uint32_t kSphereBit = 0x80000000u;
+
+struct SceneDev {
+  const float4* nodes;   // 4 per BVH node (bvh_build.h)
+  const float4* tri0;    // per triangle slot: (a.xyz, primitive id bits)
+  const float4* tri1;    //                    (b-a, material index bits)
+  const float4* tri2;    //                    (c-a, 0)
+  const float4* mat0;    // per material: (albedo.rgb, emission)
+  const int* mat1;       //               surface
+  const float4* sph0;    // per sphere: (c.xyz, r)
+  const float4* sph1;    //             (albedo.rgb, emission)
+  const int* sph2;       //             surface
+  const float4* light0;  // per light: (a.xyz, rcp_area)
+  const float4* light1;  //            (b.xyz, emission)
+  const float4* light2;  //            (c.xyz, 0)
+  const float4* light3;  //            (n.xyz, 0)
+  uint32_t num_nodes, num_tris, num_spheres, num_lights;
+  float eps, nee_threshold, rr_cap;
+  int sky;
+  uint32_t max_bounces;
+  int integrator;
+};
+
+struct CameraDev {
+  uint32_t width, height;
+  float tan_x, tan_y;  // tanf of the half angles, computed on the host (Camera.h:19-20)
+  float ox, oy, oz;    // camera origin + the caller's offset `pos` are added separately
+  float offx, offy, offz;
+  int type;
+  float focal_length, lens_radius, stretch_x, stretch_y;
+};
+
+struct Queue {
+  float4* r0;
+  float2* r1;
+  float4* s0;
+  float4* s1;
+  uint2* s2;
+  uint32_t* depth;  // bounces so far; touched only when max_bounces != 0
+};
+
+struct ShadowQueue {
+  float4* q0;  // (d.xyz, tfar = distance - eps)
+  float4* q1;  // (contribution.rgb, destination slot bits)
+};
+
+struct Counters {
+  uint32_t n_paths[2];
+  uint32_t n_shadow;
+  uint32_t pad0;
+  unsigned long long next_sample;    // ordinal of the next sample to generate
+  unsigned long long total_samples;  // band_pixels * spp of this render call
+  unsigned long long stat_paths, stat_bounces, stat_nee, stat_shadow;
+};
+
+struct RenderParams {
+  uint32_t pool;         // capacity of each queue
+  uint32_t row0;         // first row of the band
+  uint32_t band_pixels;  // (row1-row0)*width
+  uint32_t sample_base;
+  uint32_t seed32;       // seed folded to 32 bits
+};
+
+// ----------------------------------------------------------------------------
+// Geometry tests.
+
+// Triangle::intersect, reference Obj.h:110-121, on a triangle stored as
+// (a, b-a, c-a).  The comparisons keep the reference's form so that infinities
+// and NaNs from a ray parallel to the plane fall through identically.
+__device__ __forceinline__ float tri_intersect(f3 a, f3 ba, f3 ca, f3 o, f3 d) {
+  f3 roa = vsub(o, a);
+  f3 n = vcross(ba, ca);
+  f3 q = vcross(roa, d);
+  float inv = 1.0f / vdot(d, n);
+  float u = inv * -vdot(q, ca);
+  float v = inv * vdot(q, ba);
+  if (u < 0.0f || u > 1.0f || v < 0.0f || (u + v) > 1.0f) return INFINITY;
+  return inv * -vdot(n, roa);
+}
+
+// Sphere::intersect, reference Obj.h:257-268.
+__device__ __forceinline__ float sphere_intersect(f3 c, float r, f3 o, f3 d, float eps) {
+  f3 oc = vsub(o, c);
+  float B = 2.0f * vdot(d, oc);
+  float C = vsqrnorm(oc) - r * r;
+  float disc2 = B * B - 4.0f * C;
+  if (disc2 < 0.0f) return INFINITY;
+  float disc = sqrtf(disc2);
+  float t1 = (-B - disc) / 2.0f;
+  return t1 > eps ? t1 : (-B + disc) / 2.0f;
+}
+
+// Slab test of one child box against [0, tmax].  fminf/fmaxf drop a NaN operand
+// (0*inf when the origin lies on a slab plane of an axis-parallel ray), which
+// leaves that slab unconstrained: conservative.  The far end is widened by two
+// ulps so rounding never culls a box the ray touches.
+__device__ __forceinline__ bool slab(float lox, float hix, float loy, float hiy, float loz, float hiz,
+                                     f3 o, f3 inv, float tmax, float& tnear) {
+  float ax = (lox - o.x) * inv.x, bx = (hix - o.x) * inv.x;
+  float ay = (loy - o.y) * inv.y, by = (hiy - o.y) * inv.y;
+  float az = (loz - o.z) * inv.z, bz = (hiz - o.z) * inv.z;
+  float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+  float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+  tnear = tn;
+  return tn <= tf * 1.0000004f;
+}
+
+// Closest mesh hit with the rules of Mesh::intersect (reference Obj.h:184-195):
+// a hit needs eps < t; the smallest t wins and, among equal t, the lowest
+// primitive id (the linear scan keeps the first).  `stk` is this lane's column
+// of the block's LDS stack; consecutive entries are `stride` ints apart.
+__device__ __forceinline__ void mesh_closest(const SceneDev& sc, f3 o, f3 d, int* stk, int stride,
+                                             float& best_t, uint32_t& best_slot) {
+  best_t = INFINITY;
+  best_slot = kMiss;
+  if (sc.num_nodes == 0) return;
+  uint32_t best_prim = kMiss;
+  const float eps = sc.eps;
+  f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  int cur = 0;
+  int sp = 0;
+  while (true) {
+    if (cur >= 0) {
+      const float4* nd = sc.nodes + 4 * (size_t)cur;
+      float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+      float tn0, tn1;
+      bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, o, inv, best_t, tn0);
+      bool h1 = slab(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, o, inv, best_t, tn1);
+      int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+      if (h0 && h1) {
+        bool swap = tn1 < tn0;
+        stk[sp * stride] = swap ? c0 : c1;
+        sp++;
+        cur = swap ? c1 : c0;
+        continue;
+      }
+      if (h0) {
+        cur = c0;
+        continue;
+      }
+      if (h1) {
+        cur = c1;
+        continue;
+      }
+    } else {
+      uint32_t v = ~(uint32_t)cur;
+      uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
+      for (uint32_t k = 0; k < cnt; k++) {
+        uint32_t slot = first + k;
+        float4 A = sc.tri0[slot], B = sc.tri1[slot], C = sc.tri2[slot];
+        float t = tri_intersect(mk3(A.x, A.y, A.z), mk3(B.x, B.y, B.z), mk3(C.x, C.y, C.z), o, d);
+        uint32_t prim = __float_as_uint(A.w);
+        if (eps < t && (t < best_t || (t == best_t && prim < best_prim))) {
+          best_t = t;
+          best_prim = prim;
+          best_slot = slot;
+        }
+      }
+    }
+    if (sp == 0) break;
+    sp--;
+    cur = stk[sp * stride];
+  }
+}
+
+// Any mesh hit with eps < t < tfar (the interval Scene::isOccluded gives Embree,
+// reference Scene.h:216-217, ends taken open as in Mesh::intersect).
+__device__ __forceinline__ bool mesh_any(const SceneDev& sc, f3 o, f3 d, float tfar, int* stk,
+                                         int stride) {
+  if (sc.num_nodes == 0) return false;
+  const float eps = sc.eps;
+  f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  int cur = 0;
+  int sp = 0;
+  while (true) {
+    if (cur >= 0) {
+      const float4* nd = sc.nodes + 4 * (size_t)cur;
+      float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+      float tn0, tn1;
+      bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, o, inv, tfar, tn0);
+      bool h1 = slab(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, o, inv, tfar, tn1);
+      int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+      if (h0 && h1) {
+        stk[sp * stride] = c1;
+        sp++;
+        cur = c0;
+        continue;
+      }
+      if (h0) {
+        cur = c0;
+        continue;
+      }
+      if (h1) {
+        cur = c1;
+        continue;
+      }
+    } else {
+      uint32_t v = ~(uint32_t)cur;
+      uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
+      for (uint32_t k = 0; k < cnt; k++) {
+        uint32_t slot = first + k;
+        float4 A = sc.tri0[slot], B = sc.tri1[slot], C = sc.tri2[slot];
+        float t = tri_intersect(mk3(A.x, A.y, A.z), mk3(B.x, B.y, B.z), mk3(C.x, C.y, C.z), o, d);
+        if (eps < t && t < tfar) return true;
+      }
+    }
+    if (sp == 0) break;
+    sp--;
+    cur = stk[sp * stride];
+  }
+  return false;
+}
+
+// Scene::castRay, reference Scene.h:144-189: mesh first, then the spheres in
+// order (the first of equal t wins); the sphere wins only when strictly closer
+// than the mesh hit.  Returns t and an id: kMiss, kSphereBit|index, or triangle slot.
+__device__ __forceinline__ void cast_ray(const SceneDev& sc, f3 o, f3 d, int* stk, int stride,
+                                         float& t_out, uint32_t& id_out) {
+  float tfar;
+  uint32_t slot;
+  mesh_closest(sc, o, d, stk, stride, tfar, slot);
+  float ts = INFINITY;
+  uint32_t si = 0;
+  for (uint32_t i = 0; i < sc.num_spheres; i++) {
+    float4 s = sc.sph0[i];
+    float t = sphere_intersect(mk3(s.x, s.y, s.z), s.w, o, d, sc.eps);
+    if (t > sc.eps && t < ts) {
+      ts = t;
+      si = i;
+    }
+  }
+  if (ts < tfar) {
+    t_out = ts;
+    id_out = kSphereBit | si;
+    return;
+  }
+  t_out = tfar;
+  id_out = slot;  // kMiss when nothing was hit (tfar = inf)
+}
+
+// Scene::isOccluded, reference Scene.h:191-225, for a segment whose far end
+// tfar = distance - eps has been computed by the caller (distance >= 2 eps).
+__device__ __forceinline__ bool occluded(const SceneDev& sc, f3 o, f3 d, float tfar, int* stk,
+                                         int stride) {
+  for (uint32_t i = 0; i < sc.num_spheres; i++) {
+    float4 s = sc.sph0[i];
+    float t = sphere_intersect(mk3(s.x, s.y, s.z), s.w, o, d, sc.eps);
+    if (t > sc.eps && t < tfar) return true;
+  }
+  return mesh_any(sc, o, d, tfar, stk, stride);
+}
+
+// Surface normal and material of a hit (reference Scene.h:169-171,181-187;
+// Sphere::normal Obj.h:269-271).  The mesh normal is normalize(Ng) with
+// Ng = (b-a)x(c-a), not flipped towards the ray.
+__device__ __forceinline__ void hit_surface(const SceneDev& sc, uint32_t id, f3 o, f3 d, float t,
+                                            f3& n, f3& albedo, float& emission, int& surface) {
+  if (id & kSphereBit) {
+    uint32_t i = id & ~kSphereBit;
+    float4 s = sc.sph0[i];
+    float4 m = sc.sph1[i];
+    f3 p = vadd(o, vscale(d, t));
+    n = vdivs(vsub(p, mk3(s.x, s.y, s.z)), s.w);
+    albedo = mk3(m.x, m.y, m.z);
+    emission = m.w;
+    surface = sc.sph2[i];
+  } else {
+    float4 B = sc.tri1[id], C = sc.tri2[id];
+    n = vnormalized(vcross(mk3(B.x, B.y, B.z), mk3(C.x, C.y, C.z)));
+    uint32_t mi = __float_as_uint(B.w);
+    float4 m = sc.mat0[mi];
+    albedo = mk3(m.x, m.y, m.z);
+    emission = m.w;
+    surface = sc.mat1[mi];
+  }
+}
+
+// ----------------------------------------------------------------------------
+// Shading helpers, reference Integrator.h and Matrix3.cpp.
+
+// skyEmission, Integrator.h:73-85 (the comparisons widen `a` to double).
+__device__ __forceinline__ f3 sky_emission(f3 d) {
+  float a = vdot(d, vnormalized(mk3(0.2f, -0.8f, -0.4f)));
+  f3 col = mk3(0.0f, 0.0f, 0.0f);
+  if ((double)a > 0.999) {
+    col = splat3(5.0f);
+  } else if ((double)a > 0.96) {
+    col = vdivs(vdivs(vscale(vscale(splat3(5.0f), a - 0.96f), a - 0.96f), 0.999f - 0.96f),
+                0.999f - 0.96f);
+  }
+  return vadd(col, mk3(0.5f, 0.70f, 0.8f));
+}
+
+// schlickApprox, Integrator.h:45-51
+__device__ __forceinline__ float schlick(float r, float cos_t) {
+  float R0 = (r - 1.0f) / (r + 1.0f);
+  R0 *= R0;
+  float x = 1.0f - cos_t;
+  float x2 = x * x;
+  return R0 + (1.0f - R0) * x2 * x2 * x;
+}
+
+// rotMatrixVectors(a, b) * v, Matrix3.cpp:4-31.  The rotation axis b x a is not
+// normalised in the reference; that is kept.
+__device__ __forceinline__ f3 rot_vectors_apply(f3 a, f3 b, f3 v) {
+  f3 ax = vcross(b, a);
+  float c = vdot(a, b);
+  float s = vnorm(ax);
+  float m00 = c + ax.x * ax.x * (1.0f - c);
+  float m01 = ax.x * ax.y * (1.0f - c) - ax.z * s;
+  float m02 = ax.x * ax.z * (1.0f - c) + ax.y * s;
+  float m10 = m01 + 2 * ax.z * s;
+  float m11 = c + ax.y * ax.y * (1.0f - c);
+  float m12 = ax.y * ax.z * (1.0f - c) - ax.x * s;
+  float m20 = m02 - 2 * ax.y * s;
+  float m21 = m12 + 2 * ax.x * s;
+  float m22 = c + ax.z * ax.z * (1.0f - c);
+  f3 r = mk3(0.0f, 0.0f, 0.0f);
+  r.x += m00 * v.x + m01 * v.y + m02 * v.z;
+  r.y += m10 * v.x + m11 * v.y + m12 * v.z;
+  r.z += m20 * v.x + m21 * v.y + m22 * v.z;
+  return r;
+}
+
+// cosineSampleHemisphere, Integrator.h:18-25.  U*2.0f is a float product, the
+// product with M_PI is taken in double and narrowed.
+__device__ __forceinline__ f3 cosine_sample_hemisphere(uint32_t& rng) {
+  float r_sqr = pcg_uniform(rng);
+  float phi = (float)((double)(pcg_uniform(rng) * 2.0f) * 3.14159265358979323846);
+  float r = sqrtf(r_sqr);
+  float sn, cs;
+  sincosf(phi, &sn, &cs);
+  float x = cs * r;
+  float y = sn * r;
+  return mk3(x, y, sqrtf(1.0f - x * x - y * y));
+}
+
+// ----------------------------------------------------------------------------
+// Wave-level append: every lane of the wave must call this together.  Returns
+// the queue position for lanes with `take`, from one atomic per wave.
+__device__ __forceinline__ uint32_t wave_append(bool take, uint32_t* counter) {
+  unsigned long long mask = __ballot(take);
+  uint32_t total = (uint32_t)__popcll(mask);
+  uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                              __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+  uint32_t base = 0;
+  if (total) {
+    int leader = __ffsll((long long)mask) - 1;
+    int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if (lane == leader) base = atomicAdd(counter, total);
+    base = (uint32_t)__shfl((int)base, leader, 64);
+  }
+  return base + before;
+}
+
+// ----------------------------------------------------------------------------
+// Kernels.
+
+__global__ void k_init(Counters* cnt, unsigned long long total_samples) {
+  cnt->n_paths[0] = 0;
+  cnt->n_paths[1] = 0;
+  cnt->n_shadow = 0;
+  cnt->next_sample = 0;
+  cnt->total_samples = total_samples;
+}
+
+// How many new samples fit behind the `m` paths already in the queue.
+__device__ __forceinline__ uint32_t refill_count(const Counters* cnt, uint32_t m, uint32_t pool) {
+  unsigned long long left = cnt->total_samples - cnt->next_sample;
+  unsigned long long room = pool - m;
+  return (uint32_t)(left < room ? left : room);
+}
+
+// Appends primary rays for the next samples to queue `q` (reference
+// Raytracer.cpp:246-250: two jitter draws, camera ray, ray.o += pos).
+// Sample ordinal k maps to pixel (k mod band_pixels) of the band and sample
+// index sample_base + k / band_pixels, so consecutive lanes take consecutive
+// pixels.  The stream of a sample depends only on (pixel, sample index, seed).
+__global__ __launch_bounds__(256) void k_generate(Queue q, Counters* cnt, int qi, CameraDev cam,
+                                                  RenderParams rp, int use_depth) {
+  uint32_t m = cnt->n_paths[qi];
+  uint32_t g = refill_count(cnt, m, rp.pool);
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= g) return;
+  unsigned long long k = cnt->next_sample + tid;
+  uint32_t in_band = (uint32_t)(k % rp.band_pixels);
+  uint32_t sample = rp.sample_base + (uint32_t)(k / rp.band_pixels);
+  uint32_t pixel = rp.row0 * cam.width + in_band;
+  uint32_t px = pixel % cam.width, py = pixel / cam.width;
+  uint32_t rng = pcg_hash(pixel ^ pcg_hash(sample ^ pcg_hash(rp.seed32)));
+  float jx = pcg_uniform(rng);
+  float jy = pcg_uniform(rng);
+  float fx = (float)(int)px + jx - 0.5f;
+  float fy = (float)(int)py + jy - 0.5f;
+  const float W = (float)cam.width, H = (float)cam.height;
+  f3 o = mk3(cam.ox, cam.oy, cam.oz);
+  f3 d;
+  if (cam.type == 2) {  // OrthogonalCamera, Camera.h:73-79
+    o = vadd(o, mk3((2.0f * fx - W) / W * cam.stretch_x, -(2.0f * fy - H) / H * cam.stretch_y, 0.f));
+    d = mk3(0.0f, 0.0f, -1.0f);
+  } else {
+    float x = (2.0f * fx - W) / W * cam.tan_x;
+    float y = (2.0f * fy - H) / H * cam.tan_y;
+    if (cam.type == 0) {  // PerspectiveCamera, Camera.h:18-25
+      d = vnormalized(mk3(x, -y, -1.0f));
+    } else {  // ThinLensCamera, Camera.h:44-57
+      d = mk3(x, -y, -1.0f);
+      float t = -cam.focal_length / d.z;
+      f3 focal = vadd(o, vscale(d, t));
+      float r = pcg_uniform(rng);
+      float theta = (float)((double)(pcg_uniform(rng) * 2) * 3.14159265358979323846);
+      float sn, cs;
+      sincosf(theta, &sn, &cs);
+      o = vadd(o, vscale(mk3(r * cs, r * sn, 0.0f), cam.lens_radius));
+      d = vnormalized(vsub(focal, o));
+    }
+  }
+  o = vadd(o, mk3(cam.offx, cam.offy, cam.offz));
+  uint32_t slot = m + tid;
+  q.r0[slot] = make_float4(o.x, o.y, o.z, d.x);
+  q.r1[slot] = make_float2(d.y, d.z);
+  q.s0[slot] = make_float4(1.0f, 1.0f, 1.0f, -1.0f);
+  q.s1[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  q.s2[slot] = make_uint2(pixel, rng);
+  if (use_depth) q.depth[slot] = 0;
+}
+
+// After k_generate: publish the new queue length, advance the sample cursor and
+// clear the counters the next round appends to.
+__global__ void k_advance(Counters* cnt, int q_filled, int q_drained, uint32_t pool) {
+  uint32_t m = cnt->n_paths[q_filled];
+  uint32_t g = refill_count(cnt, m, pool);
+  cnt->n_paths[q_filled] = m + g;
+  cnt->next_sample += g;
+  cnt->stat_paths += g;
+  if (q_drained >= 0) cnt->n_paths[q_drained] = 0;
+  cnt->n_shadow = 0;
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_intersect(SceneDev sc, Queue q, uint2* hits,
+                                                     const Counters* cnt, int qi, int stack_entries) {
+  extern __shared__ int lds_stack[];
+  uint32_t n = cnt->n_paths[qi];
+  uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  float4 a = q.r0[i];
+  float2 b = q.r1[i];
+  float t;
+  uint32_t id;
+  cast_ray(sc, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), lds_stack + threadIdx.x, BLOCK, t, id);
+  hits[i] = make_uint2(__float_as_uint(t), id);
+}
+
+// One bounce of pathTrace (reference Integrator.h:108-285) for every path of
+// queue `qi`; survivors are appended to `out`, finished paths add their colour
+// to the per-pixel sums.
+__global__ __launch_bounds__(256) void k_shade(SceneDev sc, Queue in, Queue out, ShadowQueue sq,
+                                               const uint2* hits, Counters* cnt, int qi,
+                                               float* accum) {
+  const uint32_t n = cnt->n_paths[qi];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = i < n;
+  // Whole waves beyond the queue leave; partial waves stay for the ballots.
+  if ((i & ~63u) >= n) return;
+
+  bool alive = false, want_shadow = false, did_nee = false;
+  f3 o = mk3(0, 0, 0), d = mk3(0, 0, 0), att = mk3(0, 0, 0), col = mk3(0, 0, 0);
+  float mis_pdf = -1.0f, nee_pdf = 0.0f;
+  uint32_t pixel = 0, rng = 0, depth = 0;
+  f3 sh_d = mk3(0, 0, 0), sh_c = mk3(0, 0, 0);
+  float sh_tfar = 0.0f;
+
+  if (active) {
+    float4 r0 = in.r0[i];
+    float2 r1 = in.r1[i];
+    float4 s0 = in.s0[i];
+    float4 s1 = in.s1[i];
+    uint2 s2 = in.s2[i];
+    uint2 h = hits[i];
+    o = mk3(r0.x, r0.y, r0.z);
+    d = mk3(r0.w, r1.x, r1.y);
+    att = mk3(s0.x, s0.y, s0.z);
+    mis_pdf = s0.w;
+    col = mk3(s1.x, s1.y, s1.z);
+    nee_pdf = s1.w;
+    pixel = s2.x;
+    rng = s2.y;
+    if (sc.max_bounces) depth = in.depth[i] + 1;
+    const float t = __uint_as_float(h.x);
+    const uint32_t id = h.y;
+
+    if (id == kMiss) {  // Integrator.h:113-116
+      if (sc.sky || sc.integrator == 1) {
+        f3 sky = sky_emission(d);
+        col = (sc.integrator == 1) ? sky : vadd(col, vmul(att, sky));
+      }
+    } else {
+      f3 n3, albedo;
+      float emis;
+      int surface;
+      hit_surface(sc, id, o, d, t, n3, albedo, emis, surface);
+      if (sc.integrator == 1) {  // rayTraceNormals, Integrator.h:87-96
+        col = vadd(vscale(n3, 0.5f), splat3(0.5f));
+      } else {
+        f3 hp = vadd(vscale(d, t), o);  // :119
+        if (emis > 0.0f) {             // :135-151 (emission is a scalar, so max() is itself)
+          f3 e3 = splat3(emis);
+          if (mis_pdf > 0.0f) {
+            float sa = fabsf(-vdot(d, n3)) / nee_pdf / t / t;
+            f3 num = vscale(vscale(vmul(e3, att), mis_pdf), mis_pdf);
+            col = vadd(col, vdivs(num, 1.0f / sa / sa + mis_pdf * mis_pdf));
+          } else {
+            col = vadd(col, vmul(e3, att));
+          }
+        }
+        o = hp;  // :184
+        // Russian roulette, :189-194
+        float p = std_min(vmax3(att), sc.rr_cap);
+        bool cont = !(pcg_uniform(rng) > p);
+        if (cont && sc.max_bounces && depth >= sc.max_bounces) cont = false;
+        if (cont) {
+          alive = true;
+          att = vdivs(att, p);
+          if (surface == 2) {  // reflective, :198-205
+            float cos_t = vdot(d, n3);
+            d = vsub(d, vscale(vscale(n3, cos_t), 2.0f));
+            att = vmul(att, albedo);
+            mis_pdf = -1.0f;
+          } else if (surface == 0) {  // diffuse, :206-247
+            if (sc.num_lights != 0 && emis < sc.nee_threshold) {
+              // sampleRandomPointOnLight, Scene.h:227-235.  The light is picked with one
+              // draw of the path's generator, uniformly (the reference uses rand()%2).
+              uint32_t nl = sc.num_lights;
+              float ul = pcg_uniform(rng);
+              uint32_t li = (uint32_t)(ul * (float)nl);
+              if (li >= nl) li = nl - 1;
+              float4 L0 = sc.light0[li], L1 = sc.light1[li], L2 = sc.light2[li], L3 = sc.light3[li];
+              // Triangle::samplePoint, Obj.h:127-136
+              float u0 = pcg_uniform(rng);
+              float u1 = pcg_uniform(rng);
+              float su0 = sqrtf(u0);
+              float b0 = 1.0f - su0;
+              float b1 = u1 * su0;
+              f3 sp = vadd(vadd(vscale(mk3(L0.x, L0.y, L0.z), b0), vscale(mk3(L1.x, L1.y, L1.z), b1)),
+                           vscale(mk3(L2.x, L2.y, L2.z), 1.0f - b0 - b1));
+              nee_pdf = L0.w / (float)nl;
+              f3 to = vsub(sp, o);
+              float distance = vnorm(to);
+              f3 ld = vdivs(to, distance);
+              did_nee = true;
+              float sa = fabsf(-vdot(ld, mk3(L3.x, L3.y, L3.z))) / nee_pdf / distance / distance;
+              if (sa != 0.0f) {  // :219-223; denominator in double, narrowed for Vec3/float
+                f3 v = vscale(vmul(vscale(att, L1.w), albedo), fabsf(vdot(n3, ld)));
+                v = vdivs(v, 3.14159265358979323846f);
+                v = vscale(v, 1.0f);
+                v = vdivs(v, sa);
+                double den = (double)(1.0f / sa / sa) + (double)fabsf(vdot(ld, n3)) /
+                                                            3.14159265358979323846 *
+                                                            (double)fabsf(vdot(ld, n3)) /
+                                                            3.14159265358979323846;
+                f3 contrib = vdivs(v, (float)den);
+                if (distance < 2.0f * sc.eps) {
+                  col = vadd(col, contrib);  // isOccluded returns false at once, Scene.h:192-194
+                } else {
+                  want_shadow = true;
+                  sh_d = ld;
+                  sh_tfar = distance - sc.eps;
+                  sh_c = contrib;
+                }
+              }
+            }
+            d = rot_vectors_apply(n3, mk3(0.0f, 0.0f, 1.0f), cosine_sample_hemisphere(rng));  // :241-242
+            float cos_t = std_max(vdot(d, n3), 0.0f);
+            mis_pdf = did_nee ? (float)((double)cos_t / 3.14159265358979323846) : -1.0f;  // :244
+            att = vmul(att, albedo);
+          } else if (surface == 1) {  // specular (glass), :248-278
+            float ior = 1.0f / 2.0f;
+            float cos_t1 = -vdot(n3, d);
+            bool from_outside = cos_t1 > 0.0f;
+            if (!from_outside) {
+              cos_t1 *= -1;
+              ior = 1.0f / ior;
+              n3 = vneg(n3);
+            }
+            float cos_t2_sqr = 1.0f - ior * ior * (1.0f - cos_t1 * cos_t1);
+            bool refract = false;
+            if (cos_t2_sqr >= 0.0f) {  // no draw on total internal reflection
+              float fr = schlick(ior, from_outside ? cos_t1 : sqrtf(cos_t2_sqr));
+              refract = pcg_uniform(rng) > fr;
+            }
+            if (refract) {
+              float cos_t2 = sqrtf(cos_t2_sqr);
+              d = vadd(vscale(d, ior), vscale(n3, ior * cos_t1 - cos_t2));
+              d = vdivs(d, vnorm(d));
+            } else {
+              d = vadd(d, vscale(vscale(n3, cos_t1), 2));
+            }
+            att = vmul(att, albedo);
+            mis_pdf = -1.0f;
+          }
+          // varnish: the reference's switch has no case for it; nothing changes.
+        }
+      }
+    }
+  }
+
+  // Compaction: survivors take consecutive slots of the output queue.
+  uint32_t slot = wave_append(alive, &cnt->n_paths[qi ^ 1]);
+  if (alive) {
+    out.r0[slot] = make_float4(o.x, o.y, o.z, d.x);
+    out.r1[slot] = make_float2(d.y, d.z);
+    out.s0[slot] = make_float4(att.x, att.y, att.z, mis_pdf);
+    out.s1[slot] = make_float4(col.x, col.y, col.z, nee_pdf);
+    out.s2[slot] = make_uint2(pixel, rng);
+    if (sc.max_bounces) out.depth[slot] = depth;
+  } else if (active) {
+    // Finished: add the path's colour to its pixel's sum (Raytracer.cpp:251-253).
+    float* dst = accum + 3 * (size_t)pixel;
+    if (col.x != 0.0f) atomicAdd(dst + 0, col.x);
+    if (col.y != 0.0f) atomicAdd(dst + 1, col.y);
+    if (col.z != 0.0f) atomicAdd(dst + 2, col.z);
+  }
+  uint32_t sslot = wave_append(want_shadow, &cnt->n_shadow);
+  if (want_shadow) {
+    sq.q0[sslot] = make_float4(sh_d.x, sh_d.y, sh_d.z, sh_tfar);
+    sq.q1[sslot] = make_float4(sh_c.x, sh_c.y, sh_c.z, __uint_as_float(slot));
+  }
+  // Statistics: one atomic per wave and counter.
+  unsigned long long nee_mask = __ballot(did_nee);
+  unsigned long long act_mask = __ballot(active);
+  if ((threadIdx.x & 63u) == 0) {
+    atomicAdd(&cnt->stat_bounces, (unsigned long long)__popcll(act_mask));
+    if (nee_mask) atomicAdd(&cnt->stat_nee, (unsigned long long)__popcll(nee_mask));
+  }
+}
+
+// Traces the NEE segments queued by k_shade; an unoccluded one adds its
+// contribution to the colour of the path it belongs to (Integrator.h:217-223).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_shadow(SceneDev sc, Queue paths, ShadowQueue sq,
+                                                  Counters* cnt) {
+  extern __shared__ int lds_stack[];
+  uint32_t n = cnt->n_shadow;
+  uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+  if (j >= n) return;
+  float4 a = sq.q0[j];
+  float4 b = sq.q1[j];
+  uint32_t slot = __float_as_uint(b.w);
+  float4 r0 = paths.r0[slot];
+  bool occ = occluded(sc, mk3(r0.x, r0.y, r0.z), mk3(a.x, a.y, a.z), a.w, lds_stack + threadIdx.x, BLOCK);
+  if (!occ) {
+    float4 s1 = paths.s1[slot];
+    s1.x += b.x;
+    s1.y += b.y;
+    s1.z += b.z;
+    paths.s1[slot] = s1;
+  }
+  if (j == 0) cnt->stat_shadow += n;
+}
+
+// ----------------------------------------------------------------------------
+// Fixed-ray-set kernels (parity entry points).
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_trace_closest(SceneDev sc, const float* rays, uint32_t n,
+                                                         uint32_t* kind, uint32_t* prim, float* t_out,
+                                                         float* normal) {
+  extern __shared__ int lds_stack[];
+  uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  f3 o = mk3(rays[6 * (size_t)i], rays[6 * (size_t)i + 1], rays[6 * (size_t)i + 2]);
+  f3 d = mk3(rays[6 * (size_t)i + 3], rays[6 * (size_t)i + 4], rays[6 * (size_t)i + 5]);
+  float t;
+  uint32_t id;
+  cast_ray(sc, o, d, lds_stack + threadIdx.x, BLOCK, t, id);
+  f3 n3 = mk3(0, 0, 0);
+  if (id == kMiss) {
+    kind[i] = 0;
+    prim[i] = kMiss;
+  } else {
+    f3 albedo;
+    float emis;
+    int surface;
+    hit_surface(sc, id, o, d, t, n3, albedo, emis, surface);
+    if (id & kSphereBit) {
+      kind[i] = 2;
+      prim[i] = id & ~kSphereBit;
+    } else {
+      kind[i] = 1;
+      prim[i] = __float_as_uint(sc.tri0[id].w);
+    }
+  }
+  t_out[i] = t;
+  if (normal) {
+    normal[3 * (size_t)i] = n3.x;
+    normal[3 * (size_t)i + 1] = n3.y;
+    normal[3 * (size_t)i + 2] = n3.z;
+  }
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_trace_occluded(SceneDev sc, const float* rays,
+                                                          const float* dist, uint32_t n, uint8_t* out) {
+  extern __shared__ int lds_stack[];
+  uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+  if (i >= n) return;
+  f3 o = mk3(rays[6 * (size_t)i], rays[6 * (size_t)i + 1], rays[6 * (size_t)i + 2]);
+  f3 d = mk3(rays[6 * (size_t)i + 3], rays[6 * (size_t)i + 4], rays[6 * (size_t)i + 5]);
+  float distance = dist[i];
+  bool occ = false;
+  if (!(distance < 2.0f * sc.eps))  // Scene.h:192-194
+    occ = occluded(sc, o, d, distance - sc.eps, lds_stack + threadIdx.x, BLOCK);
+  out[i] = occ ? 1 : 0;
+}
+
+__global__ void k_resolve(const float* accum, float* out, size_t n, float spp) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = accum[i] / spp;
+}
+
+}  // namespace rtx

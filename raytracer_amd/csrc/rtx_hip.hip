@@ -1,0 +1,723 @@
+// rtx_hip.hip -- context management and the C ABI of librtx_hip.so
+// (declarations and the reference code each entry point replaces: include/rtx_capi.h).
+//
+// HIP only: there is no CPU path in this library.  Every entry point fails with
+// an error when no usable GPU is present.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rtx_capi.h"
+#include "bvh_build.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+  g_last_error = msg;
+  return code;
+}
+int fail_hip(hipError_t e, const char* what) {
+  g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+  return e == hipErrorOutOfMemory ? RTX_ERR_OUT_OF_MEMORY : RTX_ERR_HIP;
+}
+
+#define HIP_TRY(expr)                                  \
+  do {                                                 \
+    hipError_t e_ = (expr);                            \
+    if (e_ != hipSuccess) return fail_hip(e_, #expr);  \
+  } while (0)
+
+constexpr uint32_t kDefaultPool = 1u << 22;  // 4 Mi paths in flight: 2 queues * 64 B + hits + shadow = 0.7 GB
+constexpr int kTraceBlock = 128;             // threads per block of the traversal kernels
+constexpr int kPollSlots = 4;
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    if (count == 0) return hipSuccess;
+    return hipMalloc((void**)&p, count * sizeof(T));
+  }
+  hipError_t upload(const std::vector<T>& h) {
+    hipError_t e = alloc(h.size());
+    if (e != hipSuccess || h.empty()) return e;
+    return hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+struct StageTimer {
+  std::vector<hipEvent_t> ev;  // pairs (start, stop)
+  std::vector<int> kind;
+  std::vector<uint64_t> units;
+};
+
+}  // namespace
+
+struct rtx_ctx {
+  rtx_config cfg;
+  int device = 0;
+  uint32_t pool = 0;
+  float tan_x = 0, tan_y = 0;
+
+  // scene
+  bool have_scene = false;
+  DevBuf<float4> nodes, tri0, tri1, tri2, mat0, sph0, sph1, light0, light1, light2, light3;
+  DevBuf<int> mat1, sph2;
+  rtx::SceneDev scene{};
+  rtx_scene_info info{};
+  int stack_entries = 8;
+
+  // path pool
+  DevBuf<float4> r0[2], s0[2], s1[2], sq0, sq1;
+  DevBuf<float2> r1[2];
+  DevBuf<uint2> s2[2], hits;
+  DevBuf<uint32_t> depth[2];
+  DevBuf<rtx::Counters> cnt;
+  rtx::Counters* h_cnt = nullptr;  // pinned, kPollSlots entries
+  hipEvent_t poll_ev[kPollSlots]{};
+  DevBuf<float> resolve_tmp;
+
+  // stats
+  rtx_stats stats{};
+  bool profiling = false;
+  std::vector<hipEvent_t> ev_pool;
+};
+
+namespace {
+
+using rtx::Queue;
+
+Queue queue_of(rtx_ctx* c, int i) {
+  Queue q;
+  q.r0 = c->r0[i].p;
+  q.r1 = c->r1[i].p;
+  q.s0 = c->s0[i].p;
+  q.s1 = c->s1[i].p;
+  q.s2 = c->s2[i].p;
+  q.depth = c->depth[i].p;
+  return q;
+}
+
+int pick_stack_entries(uint32_t depth) {
+  const int sizes[] = {8, 16, 24, 32, 48, 64, 96, 128};
+  for (int s : sizes)
+    if ((uint32_t)s >= depth + 1) return s;
+  return -1;
+}
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+
+void free_ctx(rtx_ctx* c) {
+  if (!c) return;
+  DeviceGuard g(c->device);
+  c->nodes.release(); c->tri0.release(); c->tri1.release(); c->tri2.release();
+  c->mat0.release(); c->mat1.release(); c->sph0.release(); c->sph1.release(); c->sph2.release();
+  c->light0.release(); c->light1.release(); c->light2.release(); c->light3.release();
+  for (int i = 0; i < 2; i++) {
+    c->r0[i].release(); c->r1[i].release(); c->s0[i].release(); c->s1[i].release();
+    c->s2[i].release(); c->depth[i].release();
+  }
+  c->sq0.release(); c->sq1.release(); c->hits.release(); c->cnt.release(); c->resolve_tmp.release();
+  if (c->h_cnt) (void)hipHostFree(c->h_cnt);
+  for (int i = 0; i < kPollSlots; i++)
+    if (c->poll_ev[i]) (void)hipEventDestroy(c->poll_ev[i]);
+  for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+  delete c;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rtx_last_error(void) { return g_last_error.c_str(); }
+
+int rtx_create(const rtx_config* cfg, rtx_ctx** out) {
+  if (!cfg || !out) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_create: null argument");
+  *out = nullptr;
+  if (cfg->width == 0 || cfg->height == 0 || (uint64_t)cfg->width * cfg->height > (1ull << 30))
+    return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_create: bad image size");
+  if (cfg->camera < 0 || cfg->camera > 2 || cfg->integrator < 0 || cfg->integrator > 1)
+    return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_create: bad camera or integrator");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return fail(RTX_ERR_NO_DEVICE, "rtx_create: no HIP device (this library has no CPU path)");
+  int dev = cfg->device;
+  if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+  if (dev >= ndev) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_create: device ordinal out of range");
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(RTX_ERR_NO_DEVICE,
+                std::string("rtx_create: device is ") + prop.gcnArchName + ", kernels are built for gfx950");
+
+  rtx_ctx* c = new (std::nothrow) rtx_ctx();
+  if (!c) return fail(RTX_ERR_OUT_OF_MEMORY, "rtx_create: host allocation failed");
+  c->cfg = *cfg;
+  c->device = dev;
+  DeviceGuard g(dev);
+  if (!g.ok) {
+    delete c;
+    return fail(RTX_ERR_HIP, "rtx_create: hipSetDevice failed");
+  }
+  // Loop-invariant camera terms (Camera.h:19-20): the tanf argument is evaluated in
+  // double (M_PI) and narrowed, as in the reference.
+  {
+    const double pi = 3.14159265358979323846;
+    float W = (float)cfg->width, H = (float)cfg->height;
+    c->tan_x = tanf((float)((double)cfg->fov * pi / 180.0f / 2.0f));
+    c->tan_y = tanf((float)((double)(H / W * cfg->fov) * pi / 180.0f / 2.0f));
+  }
+  uint64_t npix = (uint64_t)cfg->width * cfg->height;
+  uint32_t pool = cfg->pool_paths ? cfg->pool_paths : kDefaultPool;
+  pool = (pool + 255u) & ~255u;
+  c->pool = pool;
+
+#define CTX_TRY(expr)                     \
+  do {                                    \
+    hipError_t e_ = (expr);               \
+    if (e_ != hipSuccess) {               \
+      int rc_ = fail_hip(e_, #expr);      \
+      free_ctx(c);                        \
+      return rc_;                         \
+    }                                     \
+  } while (0)
+
+  for (int i = 0; i < 2; i++) {
+    CTX_TRY(c->r0[i].alloc(pool));
+    CTX_TRY(c->r1[i].alloc(pool));
+    CTX_TRY(c->s0[i].alloc(pool));
+    CTX_TRY(c->s1[i].alloc(pool));
+    CTX_TRY(c->s2[i].alloc(pool));
+    if (cfg->max_bounces) CTX_TRY(c->depth[i].alloc(pool));
+  }
+  CTX_TRY(c->sq0.alloc(pool));
+  CTX_TRY(c->sq1.alloc(pool));
+  CTX_TRY(c->hits.alloc(pool));
+  CTX_TRY(c->cnt.alloc(1));
+  CTX_TRY(hipMemset(c->cnt.p, 0, sizeof(rtx::Counters)));
+  CTX_TRY(hipHostMalloc((void**)&c->h_cnt, sizeof(rtx::Counters) * kPollSlots, hipHostMallocDefault));
+  for (int i = 0; i < kPollSlots; i++) CTX_TRY(hipEventCreateWithFlags(&c->poll_ev[i], hipEventDisableTiming));
+  CTX_TRY(c->resolve_tmp.alloc(npix * 3));
+#undef CTX_TRY
+  *out = c;
+  return RTX_OK;
+}
+
+void rtx_destroy(rtx_ctx* ctx) { free_ctx(ctx); }
+
+int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
+  if (!c || !s) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_set_scene: null argument");
+  if (s->num_triangles && (!s->triangles || !s->material_index || !s->materials))
+    return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_set_scene: null geometry arrays");
+  if (s->num_spheres && !s->spheres) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_set_scene: null spheres");
+  if (s->num_triangles >= (1u << 28))
+    return fail(RTX_ERR_UNSUPPORTED, "rtx_set_scene: at most 2^28-1 triangles");
+  if (s->num_spheres >= (1u << 20)) return fail(RTX_ERR_UNSUPPORTED, "rtx_set_scene: too many spheres");
+  for (size_t i = 0; i < s->num_triangles; i++)
+    if (s->material_index[i] >= s->num_materials)
+      return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_set_scene: material index out of range");
+  DeviceGuard g(c->device);
+  if (!g.ok) return fail(RTX_ERR_HIP, "rtx_set_scene: hipSetDevice failed");
+
+  auto t_begin = std::chrono::steady_clock::now();
+  rtx::FlatBvh bvh;
+  rtx::build_bvh(s->triangles, s->num_triangles, bvh);
+  int stack_entries = pick_stack_entries(bvh.max_depth);
+  if (stack_entries < 0) return fail(RTX_ERR_UNSUPPORTED, "rtx_set_scene: BVH too deep");
+
+  const size_t nt = s->num_triangles;
+  std::vector<float4> nodes(bvh.nodes.size() / 4), t0(nt), t1(nt), t2(nt);
+  std::memcpy(nodes.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(float));
+  for (size_t slot = 0; slot < nt; slot++) {
+    uint32_t prim = bvh.order[slot];
+    const float* p = s->triangles + 9 * (size_t)prim;
+    // b-a and c-a with the reference's subtraction a + (-b) (Vec3.cpp:87-89); IEEE
+    // subtraction gives the same bits.
+    float bax = p[3] + (-p[0]), bay = p[4] + (-p[1]), baz = p[5] + (-p[2]);
+    float cax = p[6] + (-p[0]), cay = p[7] + (-p[1]), caz = p[8] + (-p[2]);
+    uint32_t mi = s->material_index[prim];
+    float fprim, fmi;
+    std::memcpy(&fprim, &prim, 4);
+    std::memcpy(&fmi, &mi, 4);
+    t0[slot] = make_float4(p[0], p[1], p[2], fprim);
+    t1[slot] = make_float4(bax, bay, baz, fmi);
+    t2[slot] = make_float4(cax, cay, caz, 0.f);
+  }
+  std::vector<float4> m0(s->num_materials);
+  std::vector<int> m1(s->num_materials);
+  for (size_t i = 0; i < s->num_materials; i++) {
+    const rtx_material& m = s->materials[i];
+    m0[i] = make_float4(m.albedo[0], m.albedo[1], m.albedo[2], m.emission);
+    m1[i] = m.surface;
+  }
+  std::vector<float4> sp0(s->num_spheres), sp1(s->num_spheres);
+  std::vector<int> sp2(s->num_spheres);
+  for (size_t i = 0; i < s->num_spheres; i++) {
+    const rtx_sphere& q = s->spheres[i];
+    sp0[i] = make_float4(q.c[0], q.c[1], q.c[2], q.r);
+    sp1[i] = make_float4(q.material.albedo[0], q.material.albedo[1], q.material.albedo[2],
+                         q.material.emission);
+    sp2[i] = q.material.surface;
+  }
+  // Light list, Scene::commit (Scene.h:129-141): triangles in order whose material
+  // emission exceeds the threshold; per light the Triangle ctor's n and rcp_area
+  // (Obj.h:107): n = normalize((b-a)x(c-b)), rcp_area = 2/|(b-a)x(c-b)|.
+  std::vector<float4> l0, l1, l2, l3;
+  for (size_t i = 0; i < nt; i++) {
+    const rtx_material& m = s->materials[s->material_index[i]];
+    if (!(m.emission > c->cfg.nee_threshold)) continue;
+    const float* p = s->triangles + 9 * i;
+    float bax = p[3] + (-p[0]), bay = p[4] + (-p[1]), baz = p[5] + (-p[2]);
+    float cbx = p[6] + (-p[3]), cby = p[7] + (-p[4]), cbz = p[8] + (-p[5]);
+    float nx = bay * cbz - baz * cby, ny = baz * cbx - bax * cbz, nz = bax * cby - bay * cbx;
+    float len = std::sqrt(nx * nx + ny * ny + nz * nz);
+    l0.push_back(make_float4(p[0], p[1], p[2], 2.0f / len));
+    l1.push_back(make_float4(p[3], p[4], p[5], m.emission));
+    l2.push_back(make_float4(p[6], p[7], p[8], 0.f));
+    l3.push_back(make_float4(nx / len, ny / len, nz / len, 0.f));
+  }
+
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(c->nodes.upload(nodes));
+  HIP_TRY(c->tri0.upload(t0));
+  HIP_TRY(c->tri1.upload(t1));
+  HIP_TRY(c->tri2.upload(t2));
+  HIP_TRY(c->mat0.upload(m0));
+  HIP_TRY(c->mat1.upload(m1));
+  HIP_TRY(c->sph0.upload(sp0));
+  HIP_TRY(c->sph1.upload(sp1));
+  HIP_TRY(c->sph2.upload(sp2));
+  HIP_TRY(c->light0.upload(l0));
+  HIP_TRY(c->light1.upload(l1));
+  HIP_TRY(c->light2.upload(l2));
+  HIP_TRY(c->light3.upload(l3));
+
+  rtx::SceneDev& d = c->scene;
+  d.nodes = c->nodes.p; d.tri0 = c->tri0.p; d.tri1 = c->tri1.p; d.tri2 = c->tri2.p;
+  d.mat0 = c->mat0.p; d.mat1 = c->mat1.p;
+  d.sph0 = c->sph0.p; d.sph1 = c->sph1.p; d.sph2 = c->sph2.p;
+  d.light0 = c->light0.p; d.light1 = c->light1.p; d.light2 = c->light2.p; d.light3 = c->light3.p;
+  d.num_nodes = (uint32_t)nodes.size() / 4;
+  d.num_tris = (uint32_t)nt;
+  d.num_spheres = (uint32_t)s->num_spheres;
+  d.num_lights = (uint32_t)l0.size();
+  d.eps = c->cfg.eps;
+  d.nee_threshold = c->cfg.nee_threshold;
+  d.rr_cap = c->cfg.rr_cap;
+  d.sky = c->cfg.sky;
+  d.max_bounces = c->cfg.max_bounces;
+  d.integrator = c->cfg.integrator;
+  c->stack_entries = stack_entries;
+  c->have_scene = true;
+  c->info.num_nodes = d.num_nodes;
+  c->info.num_triangles = d.num_tris;
+  c->info.num_lights = d.num_lights;
+  c->info.num_spheres = d.num_spheres;
+  c->info.max_depth = bvh.max_depth;
+  c->info.stack_entries = (uint32_t)stack_entries;
+  c->info.build_ms =
+      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  return RTX_OK;
+}
+
+int rtx_get_scene_info(rtx_ctx* c, rtx_scene_info* out) {
+  if (!c || !out) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_get_scene_info: null argument");
+  if (!c->have_scene) return fail(RTX_ERR_NO_SCENE, "rtx_get_scene_info: no scene set");
+  *out = c->info;
+  return RTX_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+enum StageKind { kGen = 0, kIsect = 1, kShade = 2, kShadow = 3, kOther = 4 };
+
+// Records start/stop events around a launch when profiling is on.
+struct LaunchTimer {
+  rtx_ctx* c;
+  hipStream_t st;
+  StageTimer* tm;
+  LaunchTimer(rtx_ctx* c_, hipStream_t st_, StageTimer* tm_) : c(c_), st(st_), tm(tm_) {}
+  hipEvent_t get_event() {
+    if (!c->ev_pool.empty()) {
+      hipEvent_t e = c->ev_pool.back();
+      c->ev_pool.pop_back();
+      return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+  void begin(int kind, uint64_t units) {
+    if (!tm) return;
+    hipEvent_t a = get_event(), b = get_event();
+    tm->ev.push_back(a);
+    tm->ev.push_back(b);
+    tm->kind.push_back(kind);
+    tm->units.push_back(units);
+    (void)hipEventRecord(a, st);
+  }
+  void end() {
+    if (!tm) return;
+    (void)hipEventRecord(tm->ev.back(), st);
+  }
+};
+
+uint32_t blocks_for(uint32_t n, uint32_t block) { return n == 0 ? 1u : (n + block - 1) / block; }
+
+}  // namespace
+
+extern "C" {
+
+int rtx_render(rtx_ctx* c, float* accum_dev, uint32_t spp, uint32_t sample_base, uint64_t seed,
+               const float cam_offset[3], uint32_t row0, uint32_t row1, void* stream) {
+  if (!c || !accum_dev) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render: null argument");
+  if (!c->have_scene) return fail(RTX_ERR_NO_SCENE, "rtx_render: no scene set");
+  if (row1 == 0) row1 = c->cfg.height;
+  if (row0 >= row1 || row1 > c->cfg.height)
+    return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render: bad row range");
+  if (spp == 0) return RTX_OK;
+  DeviceGuard g(c->device);
+  if (!g.ok) return fail(RTX_ERR_HIP, "rtx_render: hipSetDevice failed");
+  hipStream_t st = (hipStream_t)stream;
+
+  rtx::CameraDev cam{};
+  cam.width = c->cfg.width;
+  cam.height = c->cfg.height;
+  cam.tan_x = c->tan_x;
+  cam.tan_y = c->tan_y;
+  cam.ox = c->cfg.cam_origin[0];
+  cam.oy = c->cfg.cam_origin[1];
+  cam.oz = c->cfg.cam_origin[2];
+  cam.offx = cam_offset ? cam_offset[0] : 0.f;
+  cam.offy = cam_offset ? cam_offset[1] : 0.f;
+  cam.offz = cam_offset ? cam_offset[2] : 0.f;
+  cam.type = c->cfg.camera;
+  cam.focal_length = c->cfg.focal_length;
+  cam.lens_radius = c->cfg.lens_radius;
+  cam.stretch_x = c->cfg.stretch_x;
+  cam.stretch_y = c->cfg.stretch_y;
+
+  rtx::RenderParams rp{};
+  rp.pool = c->pool;
+  rp.row0 = row0;
+  rp.band_pixels = (row1 - row0) * c->cfg.width;
+  rp.sample_base = sample_base;
+  rp.seed32 = (uint32_t)(seed ^ (seed >> 32));
+  const unsigned long long total = (unsigned long long)rp.band_pixels * spp;
+
+  rtx::Counters* cnt = c->cnt.p;
+  rtx::ShadowQueue sq{c->sq0.p, c->sq1.p};
+  const int use_depth = c->cfg.max_bounces ? 1 : 0;
+  const size_t lds = (size_t)c->stack_entries * kTraceBlock * sizeof(int);
+  const uint32_t pool = c->pool;
+
+  StageTimer timer;
+  LaunchTimer lt(c, st, c->profiling ? &timer : nullptr);
+  uint64_t launches = 0;
+
+  // Carry the statistics across calls: read them back at the end, the device copy
+  // restarts from zero each call.
+  rtx::k_init<<<1, 1, 0, st>>>(cnt, total);
+  HIP_TRY(hipMemsetAsync(&cnt->stat_paths, 0, 4 * sizeof(unsigned long long), st));
+  launches++;
+
+  // First fill of queue 0.
+  uint32_t first = (uint32_t)std::min<unsigned long long>(total, pool);
+  lt.begin(kGen, first);
+  rtx::k_generate<<<blocks_for(first, 256), 256, 0, st>>>(queue_of(c, 0), cnt, 0, cam, rp, use_depth);
+  lt.end();
+  rtx::k_advance<<<1, 1, 0, st>>>(cnt, 0, -1, pool);
+  launches += 2;
+
+  int cur = 0;
+  uint64_t iterations = 0;
+  // Upper bounds known to the host, refreshed from polled counters.
+  uint32_t n_upper = first;
+  unsigned long long samples_left_upper = total - first;
+  int poll_head = 0, poll_pending = 0;
+  bool done = false;
+  uint64_t iters_since_poll = 0;
+
+  while (!done) {
+    const int nxt = cur ^ 1;
+    Queue qc = queue_of(c, cur), qn = queue_of(c, nxt);
+    const uint32_t n_launch = n_upper;
+    const uint32_t g_upper = (uint32_t)std::min<unsigned long long>(samples_left_upper, pool);
+
+    lt.begin(kIsect, n_launch);
+    rtx::k_intersect<kTraceBlock><<<blocks_for(n_launch, kTraceBlock), kTraceBlock, lds, st>>>(
+        c->scene, qc, c->hits.p, cnt, cur, c->stack_entries);
+    lt.end();
+    lt.begin(kShade, n_launch);
+    rtx::k_shade<<<blocks_for(n_launch, 256), 256, 0, st>>>(c->scene, qc, qn, sq, c->hits.p, cnt, cur,
+                                                            accum_dev);
+    lt.end();
+    launches += 2;
+    if (c->scene.num_lights && c->cfg.integrator == 0) {
+      lt.begin(kShadow, n_launch);
+      rtx::k_shadow<kTraceBlock><<<blocks_for(n_launch, kTraceBlock), kTraceBlock, lds, st>>>(
+          c->scene, qn, sq, cnt);
+      lt.end();
+      launches++;
+    }
+    if (g_upper) {
+      lt.begin(kGen, g_upper);
+      rtx::k_generate<<<blocks_for(g_upper, 256), 256, 0, st>>>(qn, cnt, nxt, cam, rp, use_depth);
+      lt.end();
+      launches++;
+    }
+    rtx::k_advance<<<1, 1, 0, st>>>(cnt, nxt, cur, pool);
+    launches++;
+    iterations++;
+    iters_since_poll++;
+    cur = nxt;
+
+    // While samples remain the pool refills to capacity; afterwards only a
+    // polled queue length can lower the bound.
+    if (samples_left_upper > 0) {
+      // the refill takes min(left, room); room is unknown to the host, so only the
+      // device knows next_sample exactly.  Keep the bounds conservative.
+      n_upper = pool < total ? pool : (uint32_t)total;
+    }
+
+    const uint64_t poll_every = samples_left_upper > 0 ? 4 : 8;
+    if (iters_since_poll >= poll_every) {
+      iters_since_poll = 0;
+      if (poll_pending == kPollSlots - 1) {
+        // Wait for the oldest outstanding snapshot.
+        int slot = (poll_head - poll_pending + kPollSlots * 2) % kPollSlots;
+        HIP_TRY(hipEventSynchronize(c->poll_ev[slot]));
+        const rtx::Counters& h = c->h_cnt[slot];
+        poll_pending--;
+        samples_left_upper = h.total_samples - h.next_sample;
+        if (samples_left_upper == 0) {
+          n_upper = std::min(n_upper, h.n_paths[0] + h.n_paths[1]);
+          if (n_upper == 0) done = true;
+        }
+      }
+      if (!done) {
+        HIP_TRY(hipMemcpyAsync(&c->h_cnt[poll_head], cnt, sizeof(rtx::Counters), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(c->poll_ev[poll_head], st));
+        poll_head = (poll_head + 1) % kPollSlots;
+        poll_pending++;
+      }
+    }
+    // Drain any snapshot that has already landed (no waiting).
+    while (!done && poll_pending > 0) {
+      int slot = (poll_head - poll_pending + kPollSlots * 2) % kPollSlots;
+      if (hipEventQuery(c->poll_ev[slot]) != hipSuccess) break;
+      const rtx::Counters& h = c->h_cnt[slot];
+      poll_pending--;
+      samples_left_upper = h.total_samples - h.next_sample;
+      if (samples_left_upper == 0) {
+        n_upper = std::min(n_upper, h.n_paths[0] + h.n_paths[1]);
+        if (n_upper == 0) done = true;
+      }
+    }
+  }
+  // Final statistics snapshot; also the completion barrier of this call.
+  HIP_TRY(hipMemcpyAsync(&c->h_cnt[0], cnt, sizeof(rtx::Counters), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
+  {
+    const rtx::Counters& h = c->h_cnt[0];
+    if (h.n_paths[0] + h.n_paths[1] != 0 || h.next_sample != h.total_samples)
+      return fail(RTX_ERR_HIP, "rtx_render: internal error, path queue not drained");
+    c->stats.paths += h.stat_paths;
+    c->stats.bounces += h.stat_bounces;
+    c->stats.nee_samples += h.stat_nee;
+    c->stats.shadow_rays += h.stat_shadow;
+    c->stats.iterations += iterations;
+    c->stats.launches += launches;
+  }
+  if (c->profiling) {
+    for (size_t i = 0; i < timer.kind.size(); i++) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, timer.ev[2 * i], timer.ev[2 * i + 1]);
+      switch (timer.kind[i]) {
+        case kGen:
+          c->stats.ms_generate += ms;
+          c->stats.timed_launches_generate++;
+          c->stats.timed_paths_generate += timer.units[i];
+          break;
+        case kIsect:
+          c->stats.ms_intersect += ms;
+          c->stats.timed_launches_intersect++;
+          c->stats.timed_rays_intersect += timer.units[i];
+          break;
+        case kShade:
+          c->stats.ms_shade += ms;
+          c->stats.timed_launches_shade++;
+          c->stats.timed_paths_shade += timer.units[i];
+          break;
+        case kShadow:
+          c->stats.ms_shadow += ms;
+          c->stats.timed_launches_shadow++;
+          c->stats.timed_rays_shadow += timer.units[i];
+          break;
+        default:
+          c->stats.ms_other += ms;
+      }
+    }
+    for (hipEvent_t e : timer.ev) c->ev_pool.push_back(e);
+  }
+  return RTX_OK;
+}
+
+int rtx_resolve(rtx_ctx* c, const float* accum_dev, uint32_t total_spp, float* rgb_out_host, void* stream) {
+  if (!c || !accum_dev || !rgb_out_host) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_resolve: null argument");
+  if (total_spp == 0) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_resolve: total_spp is 0");
+  DeviceGuard g(c->device);
+  if (!g.ok) return fail(RTX_ERR_HIP, "rtx_resolve: hipSetDevice failed");
+  hipStream_t st = (hipStream_t)stream;
+  size_t n = (size_t)c->cfg.width * c->cfg.height * 3;
+  rtx::k_resolve<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(accum_dev, c->resolve_tmp.p, n, (float)total_spp);
+  HIP_TRY(hipMemcpyAsync(rgb_out_host, c->resolve_tmp.p, n * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return RTX_OK;
+}
+
+int rtx_trace_closest(rtx_ctx* c, const float* rays_host, size_t n, uint32_t* kind_out, uint32_t* prim_out,
+                      float* t_out, float* normal_out) {
+  if (!c || (n && (!rays_host || !kind_out || !prim_out || !t_out)))
+    return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_trace_closest: null argument");
+  if (!c->have_scene) return fail(RTX_ERR_NO_SCENE, "rtx_trace_closest: no scene set");
+  if (n == 0) return RTX_OK;
+  if (n > 0x7fffffffu) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_trace_closest: too many rays");
+  DeviceGuard g(c->device);
+  if (!g.ok) return fail(RTX_ERR_HIP, "rtx_trace_closest: hipSetDevice failed");
+  DevBuf<float> rays, t, nrm;
+  DevBuf<uint32_t> kind, prim;
+  int rc = RTX_OK;
+  do {
+#define TRY_BREAK(expr)               \
+  {                                   \
+    hipError_t e_ = (expr);           \
+    if (e_ != hipSuccess) {           \
+      rc = fail_hip(e_, #expr);       \
+      break;                          \
+    }                                 \
+  }
+    TRY_BREAK(rays.alloc(n * 6));
+    TRY_BREAK(t.alloc(n));
+    TRY_BREAK(kind.alloc(n));
+    TRY_BREAK(prim.alloc(n));
+    if (normal_out) TRY_BREAK(nrm.alloc(n * 3));
+    TRY_BREAK(hipMemcpy(rays.p, rays_host, n * 6 * sizeof(float), hipMemcpyHostToDevice));
+    size_t lds = (size_t)c->stack_entries * kTraceBlock * sizeof(int);
+    rtx::k_trace_closest<kTraceBlock><<<blocks_for((uint32_t)n, kTraceBlock), kTraceBlock, lds, 0>>>(
+        c->scene, rays.p, (uint32_t)n, kind.p, prim.p, t.p, nrm.p);
+    TRY_BREAK(hipGetLastError());
+    TRY_BREAK(hipDeviceSynchronize());
+    TRY_BREAK(hipMemcpy(kind_out, kind.p, n * 4, hipMemcpyDeviceToHost));
+    TRY_BREAK(hipMemcpy(prim_out, prim.p, n * 4, hipMemcpyDeviceToHost));
+    TRY_BREAK(hipMemcpy(t_out, t.p, n * 4, hipMemcpyDeviceToHost));
+    if (normal_out) TRY_BREAK(hipMemcpy(normal_out, nrm.p, n * 12, hipMemcpyDeviceToHost));
+  } while (0);
+  rays.release(); t.release(); nrm.release(); kind.release(); prim.release();
+  return rc;
+}
+
+int rtx_trace_occluded(rtx_ctx* c, const float* rays_host, const float* distance_host, size_t n,
+                       uint8_t* occluded_out) {
+  if (!c || (n && (!rays_host || !distance_host || !occluded_out)))
+    return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_trace_occluded: null argument");
+  if (!c->have_scene) return fail(RTX_ERR_NO_SCENE, "rtx_trace_occluded: no scene set");
+  if (n == 0) return RTX_OK;
+  if (n > 0x7fffffffu) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_trace_occluded: too many rays");
+  DeviceGuard g(c->device);
+  if (!g.ok) return fail(RTX_ERR_HIP, "rtx_trace_occluded: hipSetDevice failed");
+  DevBuf<float> rays, dist;
+  DevBuf<uint8_t> occ;
+  int rc = RTX_OK;
+  do {
+    TRY_BREAK(rays.alloc(n * 6));
+    TRY_BREAK(dist.alloc(n));
+    TRY_BREAK(occ.alloc(n));
+    TRY_BREAK(hipMemcpy(rays.p, rays_host, n * 6 * sizeof(float), hipMemcpyHostToDevice));
+    TRY_BREAK(hipMemcpy(dist.p, distance_host, n * sizeof(float), hipMemcpyHostToDevice));
+    size_t lds = (size_t)c->stack_entries * kTraceBlock * sizeof(int);
+    rtx::k_trace_occluded<kTraceBlock><<<blocks_for((uint32_t)n, kTraceBlock), kTraceBlock, lds, 0>>>(
+        c->scene, rays.p, dist.p, (uint32_t)n, occ.p);
+    TRY_BREAK(hipGetLastError());
+    TRY_BREAK(hipDeviceSynchronize());
+    TRY_BREAK(hipMemcpy(occluded_out, occ.p, n, hipMemcpyDeviceToHost));
+  } while (0);
+#undef TRY_BREAK
+  rays.release(); dist.release(); occ.release();
+  return rc;
+}
+
+int rtx_get_stats(rtx_ctx* c, rtx_stats* out) {
+  if (!c || !out) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_get_stats: null argument");
+  *out = c->stats;
+  return RTX_OK;
+}
+int rtx_reset_stats(rtx_ctx* c) {
+  if (!c) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_reset_stats: null argument");
+  c->stats = rtx_stats{};
+  return RTX_OK;
+}
+int rtx_set_profiling(rtx_ctx* c, int on) {
+  if (!c) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_set_profiling: null argument");
+  c->profiling = on != 0;
+  return RTX_OK;
+}
+
+int rtx_accum_alloc(rtx_ctx* c, float** out) {
+  if (!c || !out) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_accum_alloc: null argument");
+  DeviceGuard g(c->device);
+  if (!g.ok) return fail(RTX_ERR_HIP, "rtx_accum_alloc: hipSetDevice failed");
+  size_t bytes = (size_t)c->cfg.width * c->cfg.height * 3 * sizeof(float);
+  HIP_TRY(hipMalloc((void**)out, bytes));
+  HIP_TRY(hipMemset(*out, 0, bytes));
+  return RTX_OK;
+}
+int rtx_accum_free(rtx_ctx* c, float* p) {
+  if (!c) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_accum_free: null argument");
+  DeviceGuard g(c->device);
+  if (p) HIP_TRY(hipFree(p));
+  return RTX_OK;
+}
+int rtx_accum_clear(rtx_ctx* c, float* p, void* stream) {
+  if (!c || !p) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_accum_clear: null argument");
+  DeviceGuard g(c->device);
+  size_t bytes = (size_t)c->cfg.width * c->cfg.height * 3 * sizeof(float);
+  HIP_TRY(hipMemsetAsync(p, 0, bytes, (hipStream_t)stream));
+  return RTX_OK;
+}
+
+}  // extern "C"

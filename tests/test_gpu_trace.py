@@ -1,0 +1,121 @@
+"""GPU parity, fixed ray sets: the HIP closest-hit / any-hit kernels against the
+oracle's first-party linear scan (Mesh::intersect order, reference Obj.h:184-195,
+combined by the castRay rules of Scene.h:144-189).  Bar: bit-exact kind, primitive
+id, t and normal for every ray."""
+import numpy as np
+import pytest
+
+from raytracer_amd import scenes
+from raytracer_amd.capi import Config, Renderer
+
+pytestmark = pytest.mark.gpu
+
+
+def camera_rays(oracle, cfg, n_side=96):
+    rays = []
+    for j in range(n_side):
+        for i in range(n_side):
+            px = (i + 0.5) * cfg.width / n_side
+            py = (j + 0.5) * cfg.height / n_side
+            o, d, _ = oracle.camera_ray(cfg, px, py)
+            rays.append(np.concatenate([o, d]))
+    return np.array(rays, np.float32)
+
+
+def bounce_rays(oracle, osc, primary, seed=3):
+    """Secondary rays leaving the primary hit points in random directions (origins lie
+    exactly on surfaces: the eps and tie rules matter here)."""
+    kind, prim, t, nrm = osc.trace_closest(primary)
+    hit = kind != 0
+    o = primary[hit, :3] + primary[hit, 3:] * t[hit, None]
+    rng = np.random.default_rng(seed)
+    d = rng.normal(size=o.shape)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.concatenate([o, d], 1).astype(np.float32)
+
+
+SCENES = {
+    "cornell": lambda: scenes.cornell(),
+    "cornell_4lights": lambda: scenes.cornell(lights=4),
+    "sphere_sky": lambda: scenes.sphere_sky(),
+    "soup10k": lambda: scenes.soup(10000, 3),
+    "one_triangle": lambda: scenes.SceneData(scenes.quad((-1, 0, 0), (1, 0, 0), (1, 2, 0), (-1, 2, 0))[:1],
+                                             np.zeros(1, np.uint32),
+                                             np.array([scenes.material(scenes.WHITE)], scenes.MATERIAL_DTYPE)),
+    "spheres_only": lambda: scenes.SceneData(np.zeros((0, 9), np.float32), np.zeros(0, np.uint32),
+                                             np.array([scenes.material(scenes.WHITE)], scenes.MATERIAL_DTYPE),
+                                             scenes.soup(1, 4).spheres),
+}
+
+
+def assert_same_hits(got, want):
+    gk, gp, gt, gn = got
+    wk, wp, wt, wn = want
+    bad = np.nonzero((gk != wk) | (gp != wp) | (gt.view(np.uint32) != wt.view(np.uint32)))[0]
+    assert bad.size == 0, (f"{bad.size} of {gk.size} rays differ; first: ray {bad[:5]}, "
+                           f"gpu (kind,prim,t)={list(zip(gk[bad[:5]], gp[bad[:5]], gt[bad[:5]]))} "
+                           f"oracle={list(zip(wk[bad[:5]], wp[bad[:5]], wt[bad[:5]]))}")
+    hit = wk != 0
+    assert np.array_equal(gn[hit].view(np.uint32), wn[hit].view(np.uint32)), "normals differ"
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_closest_hit_bit_exact(name, oracle, rtx_lib):
+    cfg = Config(width=800, height=800, pool_paths=1 << 16)
+    sc = SCENES[name]()
+    osc = oracle.OracleScene(sc, cfg)
+    with Renderer(cfg) as r:
+        r.set_scene(sc)
+        prim = camera_rays(oracle, cfg)
+        sets = [prim, bounce_rays(oracle, osc, prim), scenes.random_rays(20000, seed=11),
+                scenes.random_rays(5000, seed=12, unit=False)]
+        for rays in sets:
+            if rays.shape[0] == 0:
+                continue
+            want = osc.trace_closest(rays, use_bvh=False)
+            got = r.trace_closest(rays)
+            assert_same_hits(got, want)
+
+
+@pytest.mark.parametrize("name", ["cornell", "soup10k", "sphere_sky", "spheres_only"])
+def test_occlusion_bit_exact(name, oracle, rtx_lib):
+    cfg = Config(width=800, height=800, pool_paths=1 << 16)
+    sc = SCENES[name]()
+    osc = oracle.OracleScene(sc, cfg)
+    rng = np.random.default_rng(5)
+    rays = np.concatenate([scenes.random_rays(20000, seed=21),
+                           bounce_rays(oracle, osc, camera_rays(oracle, cfg, 64))])
+    dist = rng.uniform(0.0, 3.0, rays.shape[0]).astype(np.float32)
+    dist[:50] = rng.uniform(0.0, 0.003, 50)  # exercises distance < 2*eps (Scene.h:192-194)
+    with Renderer(cfg) as r:
+        r.set_scene(sc)
+        got = r.trace_occluded(rays, dist)
+    want = osc.trace_occluded(rays, dist, use_bvh=False)
+    assert np.array_equal(got, want), f"{np.count_nonzero(got != want)} of {got.size} segments differ"
+    assert 0 < want.sum() < want.size or name == "spheres_only"
+
+
+def test_empty_inputs(rtx_lib):
+    cfg = Config(width=16, height=16, pool_paths=1 << 12)
+    with Renderer(cfg) as r:
+        r.set_scene(scenes.cornell())
+        k, p, t, n = r.trace_closest(np.zeros((0, 6), np.float32))
+        assert k.size == 0 and t.size == 0
+        assert r.trace_occluded(np.zeros((0, 6), np.float32), np.zeros(0, np.float32)).size == 0
+
+
+def test_degenerate_rays(oracle, rtx_lib):
+    """Axis-parallel rays, rays in a triangle's plane, zero direction components: the NaN/Inf
+    fall-through of Triangle::intersect (Obj.h:116-120) must match."""
+    cfg = Config(width=800, height=800, pool_paths=1 << 12)
+    sc = scenes.cornell()
+    osc = oracle.OracleScene(sc, cfg)
+    rays = []
+    for o in [(0, 1, 3), (0, 0, 0), (0.5, 0, 0.5), (-1, 1, 0), (0, 2, 0), (0.3, 1.98, 0.1), (0, 1, 0)]:
+        for d in [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1),
+                  (1, 1, 0), (0, 1, 1), (1, 0, 1), (0.70710678, 0, -0.70710678), (1e-30, 1, 0)]:
+            rays.append(o + d)
+    rays = np.array(rays, np.float32)
+    with Renderer(cfg) as r:
+        r.set_scene(sc)
+        assert_same_hits(r.trace_closest(rays), osc.trace_closest(rays, use_bvh=False))
