@@ -357,7 +357,7 @@ inline void mesh_closest_bvh(const Scene& S, V3 o, V3 d, float& best_t, uint32_t
       for (uint32_t i = n.first; i < n.first + n.count; i++) {
         uint32_t p = S.bvh.order[i];
         float t = tri_intersect(S.tris[p], o, d);
-        if (eps < t && (t < best_t || (t == best_t && p < best_prim))) {
+        if (eps < t && t < kInf && (t < best_t || (t == best_t && p < best_prim))) {
           best_t = t;
           best_prim = p;
         }

@@ -179,7 +179,7 @@ __device__ __forceinline__ void mesh_closest(const SceneDev& sc, f3 o, f3 d, int
         float4 A = sc.tri0[slot], B = sc.tri1[slot], C = sc.tri2[slot];
         float t = tri_intersect(mk3(A.x, A.y, A.z), mk3(B.x, B.y, B.z), mk3(C.x, C.y, C.z), o, d);
         uint32_t prim = __float_as_uint(A.w);
-        if (eps < t && (t < best_t || (t == best_t && prim < best_prim))) {
+        if (eps < t && t < INFINITY && (t < best_t || (t == best_t && prim < best_prim))) {
           best_t = t;
           best_prim = prim;
           best_slot = slot;
