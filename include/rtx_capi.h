@@ -81,7 +81,12 @@ typedef struct {
   float focal_length, lens_radius; /* thin lens */
   float stretch_x, stretch_y;      /* orthogonal */
   int32_t device;        /* HIP device ordinal; -1 = the calling thread's current device */
-  uint32_t pool_paths;   /* capacity of the in-flight path pool; 0 = library default */
+  uint32_t pool_paths;   /* capacity of the in-flight path pool; 0 = library default (4 Mi paths) */
+  uint32_t finish_paths; /* once the samples are exhausted and at most this many paths are left, they
+                            are run to their end by one launch (one path per lane) instead of further
+                            rounds of small kernels; 0 = library default (131072), 1 = never */
+  uint32_t result_buffer_mib; /* budget of the per-sample result buffer (12 bytes per sample); a call
+                            with more samples is rendered in several chunks; 0 = default (8192) */
 } rtx_config;
 
 /* Scene geometry, borrowed for the duration of rtx_set_scene.
@@ -108,11 +113,9 @@ typedef struct {
   uint64_t launches;     /* kernel launches */
   /* Filled only while profiling is on (rtx_set_profiling): device time per stage,
    * measured with HIP events on the render stream, and launches timed. */
-  double ms_generate, ms_intersect, ms_shade, ms_shadow, ms_other;
+  double ms_generate, ms_intersect, ms_shade, ms_shadow, ms_finish, ms_reduce, ms_other;
   uint64_t timed_launches_intersect, timed_launches_shade, timed_launches_shadow,
       timed_launches_generate;
-  /* Units the timed launches processed (for bytes-per-launch figures). */
-  uint64_t timed_rays_intersect, timed_paths_shade, timed_rays_shadow, timed_paths_generate;
 } rtx_stats;
 
 typedef struct {
@@ -142,7 +145,8 @@ int rtx_get_scene_info(rtx_ctx* ctx, rtx_scene_info* out);
  * adds `spp` samples per pixel -- sample indices sample_base .. sample_base+spp-1 --
  * of rows [row0,row1) into accum_dev, a device buffer of width*height*3 floats
  * holding per-pixel SUMS (idx = px + py*width, the layout of Img::pixels,
- * Raytracer.cpp:49,57-59).  row1 = 0 means all rows.  cam_offset is the global
+ * Raytracer.cpp:49,57-59).  Each pixel's samples are added in sample-index order, so
+ * the result is bit-reproducible from run to run.  row1 = 0 means all rows.  cam_offset is the global
  * `pos` added to every ray origin (Raytracer.cpp:250); NULL = (0,0,0).
  * The per-path random stream depends only on (pixel, sample index, seed), so
  * disjoint sample ranges rendered on different GPUs add up to the same image as

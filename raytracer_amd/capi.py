@@ -43,6 +43,7 @@ class CConfig(C.Structure):
         ("focal_length", C.c_float), ("lens_radius", C.c_float),
         ("stretch_x", C.c_float), ("stretch_y", C.c_float),
         ("device", C.c_int32), ("pool_paths", C.c_uint32),
+        ("finish_paths", C.c_uint32), ("result_buffer_mib", C.c_uint32),
     ]
 
 
@@ -60,11 +61,10 @@ class Stats(C.Structure):
         ("paths", C.c_uint64), ("bounces", C.c_uint64), ("nee_samples", C.c_uint64),
         ("shadow_rays", C.c_uint64), ("iterations", C.c_uint64), ("launches", C.c_uint64),
         ("ms_generate", C.c_double), ("ms_intersect", C.c_double), ("ms_shade", C.c_double),
-        ("ms_shadow", C.c_double), ("ms_other", C.c_double),
+        ("ms_shadow", C.c_double), ("ms_finish", C.c_double), ("ms_reduce", C.c_double),
+        ("ms_other", C.c_double),
         ("timed_launches_intersect", C.c_uint64), ("timed_launches_shade", C.c_uint64),
         ("timed_launches_shadow", C.c_uint64), ("timed_launches_generate", C.c_uint64),
-        ("timed_rays_intersect", C.c_uint64), ("timed_paths_shade", C.c_uint64),
-        ("timed_rays_shadow", C.c_uint64), ("timed_paths_generate", C.c_uint64),
     ]
 
     def as_dict(self) -> dict:
@@ -144,6 +144,8 @@ class Config:
     stretch_y: float = 1.2
     device: int = -1
     pool_paths: int = 0
+    finish_paths: int = 0
+    result_buffer_mib: int = 0
 
     def to_c(self) -> CConfig:
         c = CConfig()
@@ -154,6 +156,7 @@ class Config:
         c.focal_length, c.lens_radius = self.focal_length, self.lens_radius
         c.stretch_x, c.stretch_y = self.stretch_x, self.stretch_y
         c.device, c.pool_paths = self.device, self.pool_paths
+        c.finish_paths, c.result_buffer_mib = self.finish_paths, self.result_buffer_mib
         return c
 
 

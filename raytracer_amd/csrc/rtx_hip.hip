@@ -38,8 +38,13 @@ int fail_hip(hipError_t e, const char* what) {
     if (e_ != hipSuccess) return fail_hip(e_, #expr);  \
   } while (0)
 
-constexpr uint32_t kDefaultPool = 1u << 22;  // 4 Mi paths in flight: 2 queues * 64 B + hits + shadow = 0.7 GB
-constexpr int kTraceBlock = 128;             // threads per block of the traversal kernels
+constexpr uint32_t kDefaultPool = 1u << 22;      // 4 Mi paths in flight: 2 queues * 64 B + hits + shadow = 0.7 GB
+constexpr uint32_t kDefaultFinish = 1u << 17;    // at most this many paths left: finish them in one launch
+constexpr uint32_t kDefaultResultMiB = 8192;     // per-sample result buffer budget
+constexpr uint32_t kSegmentTarget = 8192;        // aim for this many slots per queue segment
+constexpr uint32_t kMaxSegments = 512;
+constexpr int kTraceBlock = 128;                 // threads per block of the traversal kernels
+constexpr int kFinishBlock = 64;
 constexpr int kPollSlots = 4;
 
 template <typename T>
@@ -75,7 +80,8 @@ struct StageTimer {
 struct rtx_ctx {
   rtx_config cfg;
   int device = 0;
-  uint32_t pool = 0;
+  uint32_t pool = 0, nseg = 1, cap = 0, finish_paths = kDefaultFinish;
+  size_t result_budget_floats = 0;
   float tan_x = 0, tan_y = 0;
 
   // scene
@@ -91,10 +97,12 @@ struct rtx_ctx {
   DevBuf<float2> r1[2];
   DevBuf<uint2> s2[2], hits;
   DevBuf<uint32_t> depth[2];
-  DevBuf<rtx::Counters> cnt;
-  rtx::Counters* h_cnt = nullptr;  // pinned, kPollSlots entries
+  DevBuf<rtx::SegCounter> seg;
+  DevBuf<rtx::Summary> sum;
+  rtx::Summary* h_sum = nullptr;  // pinned, kPollSlots entries
   hipEvent_t poll_ev[kPollSlots]{};
   DevBuf<float> resolve_tmp;
+  DevBuf<float> res;  // per-sample results of the chunk being rendered (grown on demand)
 
   // stats
   rtx_stats stats{};
@@ -147,8 +155,9 @@ void free_ctx(rtx_ctx* c) {
     c->r0[i].release(); c->r1[i].release(); c->s0[i].release(); c->s1[i].release();
     c->s2[i].release(); c->depth[i].release();
   }
-  c->sq0.release(); c->sq1.release(); c->hits.release(); c->cnt.release(); c->resolve_tmp.release();
-  if (c->h_cnt) (void)hipHostFree(c->h_cnt);
+  c->sq0.release(); c->sq1.release(); c->hits.release(); c->seg.release(); c->sum.release();
+  c->resolve_tmp.release(); c->res.release();
+  if (c->h_sum) (void)hipHostFree(c->h_sum);
   for (int i = 0; i < kPollSlots; i++)
     if (c->poll_ev[i]) (void)hipEventDestroy(c->poll_ev[i]);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -199,9 +208,23 @@ int rtx_create(const rtx_config* cfg, rtx_ctx** out) {
     c->tan_y = tanf((float)((double)(H / W * cfg->fov) * pi / 180.0f / 2.0f));
   }
   uint64_t npix = (uint64_t)cfg->width * cfg->height;
-  uint32_t pool = cfg->pool_paths ? cfg->pool_paths : kDefaultPool;
-  pool = (pool + 255u) & ~255u;
+  // Queue geometry: nseg segments of cap slots (cap a multiple of 256, below 2^20 so
+  // that a segment's fill fits the 21-bit fields of its packed counter).
+  uint64_t want = cfg->pool_paths ? cfg->pool_paths : kDefaultPool;
+  if (want > (1ull << 28)) {
+    delete c;
+    return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_create: pool_paths above 2^28");
+  }
+  uint32_t nseg = (uint32_t)std::min<uint64_t>(kMaxSegments, std::max<uint64_t>(1, want / kSegmentTarget));
+  uint32_t cap = (uint32_t)((want + nseg - 1) / nseg);
+  cap = (cap + 255u) & ~255u;
+  c->nseg = nseg;
+  c->cap = cap;
+  const uint32_t pool = nseg * cap;
   c->pool = pool;
+  c->finish_paths = cfg->finish_paths ? cfg->finish_paths : kDefaultFinish;
+  c->result_budget_floats =
+      (size_t)(cfg->result_buffer_mib ? cfg->result_buffer_mib : kDefaultResultMiB) * (1u << 20) / sizeof(float);
 
 #define CTX_TRY(expr)                     \
   do {                                    \
@@ -224,9 +247,11 @@ int rtx_create(const rtx_config* cfg, rtx_ctx** out) {
   CTX_TRY(c->sq0.alloc(pool));
   CTX_TRY(c->sq1.alloc(pool));
   CTX_TRY(c->hits.alloc(pool));
-  CTX_TRY(c->cnt.alloc(1));
-  CTX_TRY(hipMemset(c->cnt.p, 0, sizeof(rtx::Counters)));
-  CTX_TRY(hipHostMalloc((void**)&c->h_cnt, sizeof(rtx::Counters) * kPollSlots, hipHostMallocDefault));
+  CTX_TRY(c->seg.alloc(nseg));
+  CTX_TRY(c->sum.alloc(1));
+  CTX_TRY(hipMemset(c->seg.p, 0, sizeof(rtx::SegCounter) * nseg));
+  CTX_TRY(hipMemset(c->sum.p, 0, sizeof(rtx::Summary)));
+  CTX_TRY(hipHostMalloc((void**)&c->h_sum, sizeof(rtx::Summary) * kPollSlots, hipHostMallocDefault));
   for (int i = 0; i < kPollSlots; i++) CTX_TRY(hipEventCreateWithFlags(&c->poll_ev[i], hipEventDisableTiming));
   CTX_TRY(c->resolve_tmp.alloc(npix * 3));
 #undef CTX_TRY
@@ -362,7 +387,7 @@ int rtx_get_scene_info(rtx_ctx* c, rtx_scene_info* out) {
 
 namespace {
 
-enum StageKind { kGen = 0, kIsect = 1, kShade = 2, kShadow = 3, kOther = 4 };
+enum StageKind { kGen = 0, kIsect = 1, kShade = 2, kShadow = 3, kFinish = 4, kReduce = 5, kOther = 6 };
 
 // Records start/stop events around a launch when profiling is on.
 struct LaunchTimer {
@@ -395,7 +420,133 @@ struct LaunchTimer {
   }
 };
 
-uint32_t blocks_for(uint32_t n, uint32_t block) { return n == 0 ? 1u : (n + block - 1) / block; }
+uint32_t div_up(uint32_t n, uint32_t d) { return n == 0 ? 1u : (n + d - 1) / d; }
+
+// Renders samples [sample_base, sample_base+spp) of the band into the result
+// buffer and folds them into accum.  One chunk = one fill/drain of the queues.
+int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::RenderParams rp,
+                 uint32_t spp, hipStream_t st, StageTimer* timer) {
+  const uint32_t nseg = c->nseg, cap = c->cap, pool = c->pool;
+  const unsigned long long total = (unsigned long long)rp.band_pixels * spp;
+  rtx::SegCounter* seg = c->seg.p;
+  rtx::Summary* sum = c->sum.p;
+  rtx::ShadowQueue sq{c->sq0.p, c->sq1.p};
+  const int use_depth = c->cfg.max_bounces ? 1 : 0;
+  const size_t lds = (size_t)c->stack_entries * kTraceBlock * sizeof(int);
+  const size_t lds_fin = (size_t)c->stack_entries * kFinishBlock * sizeof(int);
+  const bool shadows = c->scene.num_lights != 0 && c->cfg.integrator == 0;
+  LaunchTimer lt(c, st, timer);
+  uint64_t launches = 0, iterations = 0;
+
+  rtx::k_begin<<<div_up(nseg, 256), 256, 0, st>>>(seg, sum, nseg, total);
+  rtx::k_plan<<<1, 1024, 0, st>>>(seg, sum, 0, -1, nseg, cap);
+  const uint32_t first = (uint32_t)std::min<unsigned long long>(total, pool);
+  lt.begin(kGen, first);
+  rtx::k_generate<<<dim3(div_up(std::min(first, cap), 256), nseg), 256, 0, st>>>(queue_of(c, 0), seg, cam, rp,
+                                                                              use_depth);
+  lt.end();
+  launches += 3;
+
+  int cur = 0;
+  // What the host knows: upper bounds, refreshed from snapshots of the summary.
+  uint32_t seg_max_upper = std::min(first, cap);
+  uint32_t active_upper = first;
+  unsigned long long left_upper = total - first;
+  int poll_head = 0, poll_pending = 0;
+  uint64_t since_poll = 0;
+  bool finished = false;
+
+  auto absorb = [&](const rtx::Summary& h) {
+    left_upper = h.total_samples - h.next_sample;
+    if (left_upper == 0) {
+      seg_max_upper = std::min(seg_max_upper, h.active_max);
+      active_upper = std::min(active_upper, h.active_total);
+    }
+  };
+
+  while (true) {
+    if (left_upper == 0 && active_upper == 0) break;
+    if (left_upper == 0 && active_upper <= c->finish_paths) {
+      lt.begin(kFinish, active_upper);
+      rtx::k_finish<kFinishBlock><<<dim3(div_up(seg_max_upper, kFinishBlock), nseg), kFinishBlock, lds_fin, st>>>(
+          c->scene, queue_of(c, cur), seg, cur, cap, c->res.p, sum);
+      lt.end();
+      launches++;
+      finished = true;
+      break;
+    }
+    const int nxt = cur ^ 1;
+    Queue qc = queue_of(c, cur), qn = queue_of(c, nxt);
+    const uint32_t gx128 = div_up(seg_max_upper, kTraceBlock), gx256 = div_up(seg_max_upper, 256);
+    lt.begin(kIsect, active_upper);
+    rtx::k_intersect<kTraceBlock><<<dim3(gx128, nseg), kTraceBlock, lds, st>>>(c->scene, qc, c->hits.p, seg, cur, cap);
+    lt.end();
+    lt.begin(kShade, active_upper);
+    rtx::k_shade<<<dim3(gx256, nseg), 256, 0, st>>>(c->scene, qc, qn, sq, c->hits.p, seg, cur, cap, c->res.p);
+    lt.end();
+    launches += 2;
+    if (shadows) {
+      lt.begin(kShadow, active_upper);
+      rtx::k_shadow<kTraceBlock><<<dim3(gx128, nseg), kTraceBlock, lds, st>>>(c->scene, qn, sq, seg, nxt, cap);
+      lt.end();
+      launches++;
+    }
+    rtx::k_plan<<<1, 1024, 0, st>>>(seg, sum, nxt, cur, nseg, cap);
+    launches++;
+    if (left_upper > 0) {
+      lt.begin(kGen, (uint64_t)std::min<unsigned long long>(left_upper, pool));
+      rtx::k_generate<<<dim3(cap / 256, nseg), 256, 0, st>>>(qn, seg, cam, rp, use_depth);
+      lt.end();
+      launches++;
+      seg_max_upper = cap;  // the refill may top every segment up
+      active_upper = pool;
+    }
+    iterations++;
+    since_poll++;
+    cur = nxt;
+
+    const uint64_t poll_every = left_upper > 0 ? 4 : 2;
+    if (since_poll >= poll_every) {
+      since_poll = 0;
+      if (poll_pending == kPollSlots - 1) {  // ring full: wait for the oldest snapshot
+        int slot = (poll_head - poll_pending + 2 * kPollSlots) % kPollSlots;
+        HIP_TRY(hipEventSynchronize(c->poll_ev[slot]));
+        absorb(c->h_sum[slot]);
+        poll_pending--;
+      }
+      HIP_TRY(hipMemcpyAsync(&c->h_sum[poll_head], sum, sizeof(rtx::Summary), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipEventRecord(c->poll_ev[poll_head], st));
+      poll_head = (poll_head + 1) % kPollSlots;
+      poll_pending++;
+    }
+    while (poll_pending > 0) {  // take every snapshot that has already landed
+      int slot = (poll_head - poll_pending + 2 * kPollSlots) % kPollSlots;
+      if (hipEventQuery(c->poll_ev[slot]) != hipSuccess) break;
+      absorb(c->h_sum[slot]);
+      poll_pending--;
+    }
+  }
+  (void)finished;
+  // Fold the chunk's samples into the sums, in sample order.
+  const uint32_t nfloats = rp.band_pixels * 3;
+  lt.begin(kReduce, total);
+  rtx::k_reduce<<<div_up(nfloats, 256), 256, 0, st>>>(c->res.p, accum_band, nfloats, spp);
+  lt.end();
+  launches++;
+  HIP_TRY(hipMemcpyAsync(&c->h_sum[0], sum, sizeof(rtx::Summary), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipGetLastError());
+  const rtx::Summary& h = c->h_sum[0];
+  if (h.next_sample != h.total_samples)
+    return fail(RTX_ERR_HIP, "rtx_render: internal error, samples left ungenerated");
+  c->stats.paths += h.stat_paths;
+  c->stats.bounces += h.stat_bounces;
+  c->stats.nee_samples += h.stat_nee;
+  c->stats.shadow_rays += h.stat_shadow;
+  c->stats.iterations += iterations;
+  c->stats.launches += launches;
+  return RTX_OK;
+}
 
 }  // namespace
 
@@ -431,137 +582,34 @@ int rtx_render(rtx_ctx* c, float* accum_dev, uint32_t spp, uint32_t sample_base,
   cam.stretch_y = c->cfg.stretch_y;
 
   rtx::RenderParams rp{};
-  rp.pool = c->pool;
+  rp.nseg = c->nseg;
+  rp.cap = c->cap;
   rp.row0 = row0;
   rp.band_pixels = (row1 - row0) * c->cfg.width;
-  rp.sample_base = sample_base;
   rp.seed32 = (uint32_t)(seed ^ (seed >> 32));
-  const unsigned long long total = (unsigned long long)rp.band_pixels * spp;
 
-  rtx::Counters* cnt = c->cnt.p;
-  rtx::ShadowQueue sq{c->sq0.p, c->sq1.p};
-  const int use_depth = c->cfg.max_bounces ? 1 : 0;
-  const size_t lds = (size_t)c->stack_entries * kTraceBlock * sizeof(int);
-  const uint32_t pool = c->pool;
+  // The result buffer holds 3 floats per sample of a chunk; a call with more
+  // samples than fit is rendered as several chunks of whole samples-per-pixel.
+  const size_t per_spp = (size_t)rp.band_pixels * 3;
+  size_t chunk_spp = c->result_budget_floats / per_spp;
+  const size_t ordinal_limit = 0xffffffffull / rp.band_pixels;  // ordinals are 32-bit
+  chunk_spp = std::min(chunk_spp, ordinal_limit);
+  if (chunk_spp == 0)
+    return fail(RTX_ERR_OUT_OF_MEMORY, "rtx_render: result_buffer_mib too small for one sample per pixel");
+  chunk_spp = std::min<size_t>(chunk_spp, spp);
+  if (c->res.n < chunk_spp * per_spp) {
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(c->res.alloc(chunk_spp * per_spp));
+  }
 
   StageTimer timer;
-  LaunchTimer lt(c, st, c->profiling ? &timer : nullptr);
-  uint64_t launches = 0;
-
-  // Carry the statistics across calls: read them back at the end, the device copy
-  // restarts from zero each call.
-  rtx::k_init<<<1, 1, 0, st>>>(cnt, total);
-  HIP_TRY(hipMemsetAsync(&cnt->stat_paths, 0, 4 * sizeof(unsigned long long), st));
-  launches++;
-
-  // First fill of queue 0.
-  uint32_t first = (uint32_t)std::min<unsigned long long>(total, pool);
-  lt.begin(kGen, first);
-  rtx::k_generate<<<blocks_for(first, 256), 256, 0, st>>>(queue_of(c, 0), cnt, 0, cam, rp, use_depth);
-  lt.end();
-  rtx::k_advance<<<1, 1, 0, st>>>(cnt, 0, -1, pool);
-  launches += 2;
-
-  int cur = 0;
-  uint64_t iterations = 0;
-  // Upper bounds known to the host, refreshed from polled counters.
-  uint32_t n_upper = first;
-  unsigned long long samples_left_upper = total - first;
-  int poll_head = 0, poll_pending = 0;
-  bool done = false;
-  uint64_t iters_since_poll = 0;
-
-  while (!done) {
-    const int nxt = cur ^ 1;
-    Queue qc = queue_of(c, cur), qn = queue_of(c, nxt);
-    const uint32_t n_launch = n_upper;
-    const uint32_t g_upper = (uint32_t)std::min<unsigned long long>(samples_left_upper, pool);
-
-    lt.begin(kIsect, n_launch);
-    rtx::k_intersect<kTraceBlock><<<blocks_for(n_launch, kTraceBlock), kTraceBlock, lds, st>>>(
-        c->scene, qc, c->hits.p, cnt, cur, c->stack_entries);
-    lt.end();
-    lt.begin(kShade, n_launch);
-    rtx::k_shade<<<blocks_for(n_launch, 256), 256, 0, st>>>(c->scene, qc, qn, sq, c->hits.p, cnt, cur,
-                                                            accum_dev);
-    lt.end();
-    launches += 2;
-    if (c->scene.num_lights && c->cfg.integrator == 0) {
-      lt.begin(kShadow, n_launch);
-      rtx::k_shadow<kTraceBlock><<<blocks_for(n_launch, kTraceBlock), kTraceBlock, lds, st>>>(
-          c->scene, qn, sq, cnt);
-      lt.end();
-      launches++;
-    }
-    if (g_upper) {
-      lt.begin(kGen, g_upper);
-      rtx::k_generate<<<blocks_for(g_upper, 256), 256, 0, st>>>(qn, cnt, nxt, cam, rp, use_depth);
-      lt.end();
-      launches++;
-    }
-    rtx::k_advance<<<1, 1, 0, st>>>(cnt, nxt, cur, pool);
-    launches++;
-    iterations++;
-    iters_since_poll++;
-    cur = nxt;
-
-    // While samples remain the pool refills to capacity; afterwards only a
-    // polled queue length can lower the bound.
-    if (samples_left_upper > 0) {
-      // the refill takes min(left, room); room is unknown to the host, so only the
-      // device knows next_sample exactly.  Keep the bounds conservative.
-      n_upper = pool < total ? pool : (uint32_t)total;
-    }
-
-    const uint64_t poll_every = samples_left_upper > 0 ? 4 : 8;
-    if (iters_since_poll >= poll_every) {
-      iters_since_poll = 0;
-      if (poll_pending == kPollSlots - 1) {
-        // Wait for the oldest outstanding snapshot.
-        int slot = (poll_head - poll_pending + kPollSlots * 2) % kPollSlots;
-        HIP_TRY(hipEventSynchronize(c->poll_ev[slot]));
-        const rtx::Counters& h = c->h_cnt[slot];
-        poll_pending--;
-        samples_left_upper = h.total_samples - h.next_sample;
-        if (samples_left_upper == 0) {
-          n_upper = std::min(n_upper, h.n_paths[0] + h.n_paths[1]);
-          if (n_upper == 0) done = true;
-        }
-      }
-      if (!done) {
-        HIP_TRY(hipMemcpyAsync(&c->h_cnt[poll_head], cnt, sizeof(rtx::Counters), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipEventRecord(c->poll_ev[poll_head], st));
-        poll_head = (poll_head + 1) % kPollSlots;
-        poll_pending++;
-      }
-    }
-    // Drain any snapshot that has already landed (no waiting).
-    while (!done && poll_pending > 0) {
-      int slot = (poll_head - poll_pending + kPollSlots * 2) % kPollSlots;
-      if (hipEventQuery(c->poll_ev[slot]) != hipSuccess) break;
-      const rtx::Counters& h = c->h_cnt[slot];
-      poll_pending--;
-      samples_left_upper = h.total_samples - h.next_sample;
-      if (samples_left_upper == 0) {
-        n_upper = std::min(n_upper, h.n_paths[0] + h.n_paths[1]);
-        if (n_upper == 0) done = true;
-      }
-    }
-  }
-  // Final statistics snapshot; also the completion barrier of this call.
-  HIP_TRY(hipMemcpyAsync(&c->h_cnt[0], cnt, sizeof(rtx::Counters), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  HIP_TRY(hipGetLastError());
-  {
-    const rtx::Counters& h = c->h_cnt[0];
-    if (h.n_paths[0] + h.n_paths[1] != 0 || h.next_sample != h.total_samples)
-      return fail(RTX_ERR_HIP, "rtx_render: internal error, path queue not drained");
-    c->stats.paths += h.stat_paths;
-    c->stats.bounces += h.stat_bounces;
-    c->stats.nee_samples += h.stat_nee;
-    c->stats.shadow_rays += h.stat_shadow;
-    c->stats.iterations += iterations;
-    c->stats.launches += launches;
+  float* accum_band = accum_dev + (size_t)row0 * c->cfg.width * 3;
+  int rc = RTX_OK;
+  for (uint32_t done = 0; done < spp && rc == RTX_OK;) {
+    const uint32_t n = (uint32_t)std::min<size_t>(chunk_spp, spp - done);
+    rp.sample_base = sample_base + done;
+    rc = render_chunk(c, accum_band, cam, rp, n, st, c->profiling ? &timer : nullptr);
+    done += n;
   }
   if (c->profiling) {
     for (size_t i = 0; i < timer.kind.size(); i++) {
@@ -571,22 +619,24 @@ int rtx_render(rtx_ctx* c, float* accum_dev, uint32_t spp, uint32_t sample_base,
         case kGen:
           c->stats.ms_generate += ms;
           c->stats.timed_launches_generate++;
-          c->stats.timed_paths_generate += timer.units[i];
           break;
         case kIsect:
           c->stats.ms_intersect += ms;
           c->stats.timed_launches_intersect++;
-          c->stats.timed_rays_intersect += timer.units[i];
           break;
         case kShade:
           c->stats.ms_shade += ms;
           c->stats.timed_launches_shade++;
-          c->stats.timed_paths_shade += timer.units[i];
           break;
         case kShadow:
           c->stats.ms_shadow += ms;
           c->stats.timed_launches_shadow++;
-          c->stats.timed_rays_shadow += timer.units[i];
+          break;
+        case kFinish:
+          c->stats.ms_finish += ms;
+          break;
+        case kReduce:
+          c->stats.ms_reduce += ms;
           break;
         default:
           c->stats.ms_other += ms;
@@ -594,7 +644,7 @@ int rtx_render(rtx_ctx* c, float* accum_dev, uint32_t spp, uint32_t sample_base,
     }
     for (hipEvent_t e : timer.ev) c->ev_pool.push_back(e);
   }
-  return RTX_OK;
+  return rc;
 }
 
 int rtx_resolve(rtx_ctx* c, const float* accum_dev, uint32_t total_spp, float* rgb_out_host, void* stream) {
@@ -638,7 +688,7 @@ int rtx_trace_closest(rtx_ctx* c, const float* rays_host, size_t n, uint32_t* ki
     if (normal_out) TRY_BREAK(nrm.alloc(n * 3));
     TRY_BREAK(hipMemcpy(rays.p, rays_host, n * 6 * sizeof(float), hipMemcpyHostToDevice));
     size_t lds = (size_t)c->stack_entries * kTraceBlock * sizeof(int);
-    rtx::k_trace_closest<kTraceBlock><<<blocks_for((uint32_t)n, kTraceBlock), kTraceBlock, lds, 0>>>(
+    rtx::k_trace_closest<kTraceBlock><<<div_up((uint32_t)n, kTraceBlock), kTraceBlock, lds, 0>>>(
         c->scene, rays.p, (uint32_t)n, kind.p, prim.p, t.p, nrm.p);
     TRY_BREAK(hipGetLastError());
     TRY_BREAK(hipDeviceSynchronize());
@@ -670,7 +720,7 @@ int rtx_trace_occluded(rtx_ctx* c, const float* rays_host, const float* distance
     TRY_BREAK(hipMemcpy(rays.p, rays_host, n * 6 * sizeof(float), hipMemcpyHostToDevice));
     TRY_BREAK(hipMemcpy(dist.p, distance_host, n * sizeof(float), hipMemcpyHostToDevice));
     size_t lds = (size_t)c->stack_entries * kTraceBlock * sizeof(int);
-    rtx::k_trace_occluded<kTraceBlock><<<blocks_for((uint32_t)n, kTraceBlock), kTraceBlock, lds, 0>>>(
+    rtx::k_trace_occluded<kTraceBlock><<<div_up((uint32_t)n, kTraceBlock), kTraceBlock, lds, 0>>>(
         c->scene, rays.p, dist.p, (uint32_t)n, occ.p);
     TRY_BREAK(hipGetLastError());
     TRY_BREAK(hipDeviceSynchronize());

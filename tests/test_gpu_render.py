@@ -51,17 +51,19 @@ def test_normals_integrator_bit_exact(oracle, rtx_lib):
         assert st.paths == 160 * 120 * 2 and st.bounces == ost.bounces
 
 
+@pytest.mark.parametrize("finish_paths", [0, 1], ids=["finish_default", "wavefront_only"])
 @pytest.mark.parametrize("name,sky,camera", [
     ("cornell", 0, 0), ("cornell_4l", 0, 0), ("sample1", 1, 0), ("sample2", 1, 0),
     ("cornell_thinlens", 0, 1), ("cornell_ortho", 0, 2), ("soup", 1, 0),
 ])
-def test_one_spp_per_path_parity(name, sky, camera, oracle, rtx_lib):
+def test_one_spp_per_path_parity(name, sky, camera, finish_paths, oracle, rtx_lib):
     sc = {"cornell": scenes.cornell, "cornell_4l": lambda: scenes.cornell(lights=4),
           "sample1": scenes.sphere_sky, "sample2": lambda: scenes.sphere_sky(glass=True),
           "cornell_thinlens": scenes.cornell, "cornell_ortho": scenes.cornell,
           "soup": lambda: scenes.soup(3000, 3)}[name]()
     cfg = Config(width=128, height=128, sky=sky, camera=camera, fov=60.0 if camera == 1 else 50.0,
-                 pool_paths=1 << 12)  # pool < pixels: the queue is refilled several times
+                 pool_paths=1 << 12,  # pool < pixels: the queue is refilled several times
+                 finish_paths=finish_paths)
     want, ost = oracle.OracleScene(sc, cfg).render(1)
     got, st, _ = gpu_render(cfg, sc, 1)
     assert st.paths == ost.paths == 128 * 128
@@ -102,18 +104,36 @@ def test_oven_box_is_one(rtx_lib):
     assert st.nee_samples == 0  # emission 0.5 >= threshold: NEE is skipped (Integrator.h:209)
 
 
-def test_sample_ranges_and_row_bands_add_up(rtx_lib):
-    """Disjoint sample ranges (what different GPUs render) and row bands (tiles) add up to
-    the one-call image; only the float summation order differs."""
+def test_sample_ranges_row_bands_and_chunks_are_bit_identical(rtx_lib):
+    """Samples are added per pixel in sample-index order, whatever the queue order was:
+    consecutive sample ranges, row bands (tiles), result-buffer chunks, another pool size
+    and a second run all give the same bits."""
     sc = scenes.cornell()
     cfg = Config(width=96, height=64, pool_paths=1 << 12)
     whole, st, _ = gpu_render(cfg, sc, 8)
+    again, _, _ = gpu_render(cfg, sc, 8)
     split, st2, _ = gpu_render(cfg, sc, 0, calls=[dict(spp=3, sample_base=0), dict(spp=5, sample_base=3)])
     bands, st3, _ = gpu_render(cfg, sc, 0, calls=[dict(spp=8, row0=0, row1=20), dict(spp=8, row0=20, row1=64)])
-    np.testing.assert_allclose(split, whole, rtol=2e-5, atol=1e-6)
-    np.testing.assert_allclose(bands, whole, rtol=2e-5, atol=1e-6)
-    assert st.paths == st2.paths == st3.paths == 96 * 64 * 8
-    assert st.bounces == st2.bounces == st3.bounces
+    # 96*64*12 B = 72 KiB per spp: a 1 MiB result buffer forces chunks of 14... use 3 spp by hand
+    chunked, st4, _ = gpu_render(Config(width=96, height=64, pool_paths=1 << 14, finish_paths=1,
+                                        result_buffer_mib=1), sc, 0,
+                                 calls=[dict(spp=8)])
+    for other in (again, split, bands, chunked):
+        assert np.array_equal(other.view(np.uint32), whole.view(np.uint32))
+    assert st.paths == st2.paths == st3.paths == st4.paths == 96 * 64 * 8
+    assert st.bounces == st2.bounces == st3.bounces == st4.bounces
+    assert st.nee_samples == st4.nee_samples and st.shadow_rays == st4.shadow_rays
+
+
+def test_result_buffer_chunking(rtx_lib):
+    """A result buffer smaller than the call's samples: the call is rendered in chunks."""
+    sc = scenes.cornell()
+    big = Config(width=256, height=256, pool_paths=1 << 15)          # 768 KiB per spp
+    small = Config(width=256, height=256, pool_paths=1 << 15, result_buffer_mib=2)  # 2 spp per chunk
+    a, sa, _ = gpu_render(big, sc, 5)
+    b, sb, _ = gpu_render(small, sc, 5)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert sa.bounces == sb.bounces and sa.paths == sb.paths
 
 
 def test_max_bounces_cap(oracle, rtx_lib):
