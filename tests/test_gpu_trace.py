@@ -119,3 +119,37 @@ def test_degenerate_rays(oracle, rtx_lib):
     with Renderer(cfg) as r:
         r.set_scene(sc)
         assert_same_hits(r.trace_closest(rays), osc.trace_closest(rays, use_bvh=False))
+
+
+@pytest.mark.parametrize("name,make", [("cornell", scenes.cornell), ("soup2k", lambda: scenes.soup(2000, 3, seed=4))])
+def test_matches_committed_vectors(name, make, rtx_lib):
+    """The committed fixed ray sets (tests/golden/make_golden.py): bit-exact kind, id, t and occlusion."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", f"closest_{name}.npz"))
+    with Renderer(Config(width=800, height=800, pool_paths=1 << 12)) as r:
+        r.set_scene(make())
+        kind, prim, t, _ = r.trace_closest(g["rays"])
+        occ = r.trace_occluded(g["rays"], g["dist"])
+    assert np.array_equal(kind, g["kind"]) and np.array_equal(prim, g["prim"])
+    assert np.array_equal(t.view(np.uint32), g["t_bits"])
+    assert np.array_equal(occ, g["occluded"])
+
+
+def test_million_triangle_mesh_bit_exact(oracle, rtx_lib):
+    """BASELINE's ~1M-triangle configuration: closest hits against the oracle.  The linear
+    scan is too slow at this size, so the oracle's BVH (itself checked against the linear
+    scan on smaller scenes) is the comparator; a sample of the rays is also checked against
+    the linear scan."""
+    sc = scenes.terrain(707)
+    cfg = Config(width=1920, height=1080, pool_paths=1 << 16)
+    osc = oracle.OracleScene(sc, cfg)
+    rays = np.concatenate([camera_rays(oracle, cfg, 64), scenes.random_rays(20000, seed=5)])
+    rays = np.concatenate([rays, bounce_rays(oracle, osc, rays[:4096])])
+    with Renderer(cfg) as r:
+        info = r.set_scene(sc)
+        got = r.trace_closest(rays)
+    assert info.num_triangles == 999710 and info.max_depth < info.stack_entries
+    assert_same_hits(got, osc.trace_closest(rays, use_bvh=True))
+    sub = rays[::97]
+    want = osc.trace_closest(sub, use_bvh=False)
+    assert np.array_equal(got[1][::97], want[1]) and np.array_equal(got[2][::97].view(np.uint32), want[2].view(np.uint32))
