@@ -53,6 +53,18 @@ def workloads():
     }
 
 
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE over this same command, reduced by tools/pmc_traffic.py).
+    Counters cannot be read from inside this process, so the figure comes from the file."""
+    path = os.path.join(ROOT, "profiles", f"pmc_traffic_{workload}.json")
+    try:
+        k = json.load(open(path))["kernels"][kernel]
+        return round(k["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT)
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def cpu_baseline(sc, cfg, spp_full, budget_s=12.0):
     """Times the oracle (OpenMP rows, dynamic schedule) on a bounded sample: the same
     frame at as many samples per pixel as fit the time budget."""
@@ -181,8 +193,10 @@ def main():
             bytes_per_launch = BYTES[dom] * units / launches
             avg_ms = ms / launches
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            traffic, traffic_src = pmc_traffic(args.workload, "k_" + dom)
             roof = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(bytes_per_launch),
                     "algorithmic_bytes_per_unit": BYTES[dom], "units_per_launch": round(units / launches, 1),
                     "avg_launch_ms": round(avg_ms, 5), "launches": int(launches)}
     if world > 1:
