@@ -94,7 +94,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("RTX_LIB") or LIB_PATH  # RTX_LIB: another build of the same library (A/B runs)
     if not os.path.exists(p):
         raise ImportError(
             f"{p} not found: build it with `make -C raytracer_amd/csrc` "

@@ -11,7 +11,6 @@ namespace rtx {
 namespace {
 
 constexpr int kBins = 16;
-constexpr uint32_t kMaxLeaf = 4;       // a node with more triangles is always split
 constexpr uint32_t kMaxSahDepth = 40;  // below this depth, fall back to median splits
 
 struct Box {
@@ -53,8 +52,10 @@ struct Builder {
   std::vector<uint32_t>& order;
   std::vector<TmpNode> nodes;
 
-  Builder(const std::vector<Box>& tb_, const std::vector<float>& c_, std::vector<uint32_t>& o_)
-      : tb(tb_), cent(c_), order(o_) {}
+  uint32_t kMaxLeaf;  // a node with more triangles is always split
+
+  Builder(const std::vector<Box>& tb_, const std::vector<float>& c_, std::vector<uint32_t>& o_, uint32_t max_leaf)
+      : tb(tb_), cent(c_), order(o_), kMaxLeaf(max_leaf) {}
 
   int32_t build(uint32_t first, uint32_t count, uint32_t depth) {
     int32_t id = (int32_t)nodes.size();
@@ -204,7 +205,8 @@ struct Flattener {
 
 }  // namespace
 
-void build_bvh(const float* tris, size_t ntri, FlatBvh& out) {
+void build_bvh(const float* tris, size_t ntri, uint32_t max_leaf, FlatBvh& out) {
+  const uint32_t kMaxLeaf = max_leaf < 1 ? 1u : (max_leaf > 8 ? 8u : max_leaf);
   out.nodes.clear();
   out.order.clear();
   out.max_depth = 0;
@@ -220,7 +222,7 @@ void build_bvh(const float* tris, size_t ntri, FlatBvh& out) {
   }
   out.order.resize(ntri);
   for (size_t i = 0; i < ntri; i++) out.order[i] = (uint32_t)i;
-  Builder b(tb, cent, out.order);
+  Builder b(tb, cent, out.order, kMaxLeaf);
   b.nodes.reserve(ntri);
   int32_t root = b.build(0, (uint32_t)ntri, 0);
 

@@ -43,6 +43,10 @@ namespace rtx {
 
 constexpr uint32_t kMiss = 0xffffffffu;
 constexpr uint32_t kSphereBit = 0x80000000u;
+// Traversal cursor value for "nothing left".  It cannot collide with a leaf
+// reference: ~0x80000000 would be a leaf of 8 triangles at slot 2^28-1, and the
+// builder makes leaves of at most 4.
+constexpr int kTraversalDone = (int)0x80000000u;
 
 struct SceneDev {
   const float4* nodes;   // 4 per BVH node (bvh_build.h)
@@ -121,6 +125,43 @@ struct RenderParams {
   uint32_t seed32;       // seed folded to 32 bits
 };
 
+// Where the traversal kernels read the BVH and the triangles from: the global
+// arrays of SceneDev, or a copy of them in LDS (scenes of a few hundred
+// triangles: every lane's node and triangle fetches then cost an LDS read
+// instead of an L1/L2 round trip, and stop competing for the L1's 64 B/clk).
+struct Geom {
+  const float4* nodes;
+  const float4* tri0;
+  const float4* tri1;
+  const float4* tri2;
+};
+__device__ __forceinline__ Geom global_geom(const SceneDev& sc) {
+  Geom g;
+  g.nodes = sc.nodes;
+  g.tri0 = sc.tri0;
+  g.tri1 = sc.tri1;
+  g.tri2 = sc.tri2;
+  return g;
+}
+// Copies [nodes | tri0 | tri1 | tri2] into `dst` (LDS) with the whole block and
+// returns the view; ends with a barrier, so every thread of the block must call it.
+__device__ __forceinline__ Geom stage_geom_lds(const SceneDev& sc, float4* dst, int tid, int nthreads) {
+  const uint32_t nn = 4 * sc.num_nodes, nt = sc.num_tris;
+  for (uint32_t k = tid; k < nn; k += nthreads) dst[k] = sc.nodes[k];
+  for (uint32_t k = tid; k < nt; k += nthreads) {
+    dst[nn + k] = sc.tri0[k];
+    dst[nn + nt + k] = sc.tri1[k];
+    dst[nn + 2 * nt + k] = sc.tri2[k];
+  }
+  __syncthreads();
+  Geom g;
+  g.nodes = dst;
+  g.tri0 = dst + nn;
+  g.tri1 = dst + nn + nt;
+  g.tri2 = dst + nn + 2 * nt;
+  return g;
+}
+
 // ----------------------------------------------------------------------------
 // Geometry tests.
 
@@ -169,8 +210,8 @@ __device__ __forceinline__ bool slab(float lox, float hix, float loy, float hiy,
 // a hit needs eps < t; the smallest t wins and, among equal t, the lowest
 // primitive id (the linear scan keeps the first).  `stk` is this lane's column
 // of the block's LDS stack; consecutive entries are `stride` ints apart.
-__device__ __forceinline__ void mesh_closest(const SceneDev& sc, f3 o, f3 d, int* stk, int stride,
-                                             float& best_t, uint32_t& best_slot) {
+__device__ __forceinline__ void mesh_closest(const SceneDev& sc, const Geom& g, f3 o, f3 d, int* stk,
+                                             int stride, float& best_t, uint32_t& best_slot) {
   best_t = INFINITY;
   best_slot = kMiss;
   if (sc.num_nodes == 0) return;
@@ -179,9 +220,12 @@ __device__ __forceinline__ void mesh_closest(const SceneDev& sc, f3 o, f3 d, int
   f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   int cur = 0;
   int sp = 0;
-  while (true) {
-    if (cur >= 0) {
-      const float4* nd = sc.nodes + 4 * (size_t)cur;
+  // "while-while" traversal: all lanes of the wave first walk inner nodes until each
+  // holds a leaf (or is done), then all test triangles; the two phases do not mix
+  // within an iteration, which keeps more lanes busy in each.
+  while (cur != kTraversalDone) {
+    while (cur >= 0) {
+      const float4* nd = g.nodes + 4 * (size_t)cur;
       float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
       float tn0, tn1;
       bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, o, inv, best_t, tn0);
@@ -192,22 +236,23 @@ __device__ __forceinline__ void mesh_closest(const SceneDev& sc, f3 o, f3 d, int
         stk[sp * stride] = swap ? c0 : c1;
         sp++;
         cur = swap ? c1 : c0;
-        continue;
-      }
-      if (h0) {
+      } else if (h0) {
         cur = c0;
-        continue;
-      }
-      if (h1) {
+      } else if (h1) {
         cur = c1;
-        continue;
+      } else if (sp == 0) {
+        cur = kTraversalDone;
+      } else {
+        sp--;
+        cur = stk[sp * stride];
       }
-    } else {
+    }
+    while (cur < 0 && cur != kTraversalDone) {
       uint32_t v = ~(uint32_t)cur;
       uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
       for (uint32_t k = 0; k < cnt; k++) {
         uint32_t slot = first + k;
-        float4 A = sc.tri0[slot], B = sc.tri1[slot], C = sc.tri2[slot];
+        float4 A = g.tri0[slot], B = g.tri1[slot], C = g.tri2[slot];
         float t = tri_intersect(mk3(A.x, A.y, A.z), mk3(B.x, B.y, B.z), mk3(C.x, C.y, C.z), o, d);
         uint32_t prim = __float_as_uint(A.w);
         if (eps < t && t < INFINITY && (t < best_t || (t == best_t && prim < best_prim))) {
@@ -216,25 +261,29 @@ __device__ __forceinline__ void mesh_closest(const SceneDev& sc, f3 o, f3 d, int
           best_slot = slot;
         }
       }
+      if (sp == 0) {
+        cur = kTraversalDone;
+      } else {
+        sp--;
+        cur = stk[sp * stride];
+      }
     }
-    if (sp == 0) break;
-    sp--;
-    cur = stk[sp * stride];
   }
 }
 
 // Any mesh hit with eps < t < tfar (the interval Scene::isOccluded gives Embree,
 // reference Scene.h:216-217, ends taken open as in Mesh::intersect).
-__device__ __forceinline__ bool mesh_any(const SceneDev& sc, f3 o, f3 d, float tfar, int* stk,
-                                         int stride) {
+__device__ __forceinline__ bool mesh_any(const SceneDev& sc, const Geom& g, f3 o, f3 d, float tfar,
+                                         int* stk, int stride) {
   if (sc.num_nodes == 0) return false;
   const float eps = sc.eps;
   f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   int cur = 0;
   int sp = 0;
-  while (true) {
-    if (cur >= 0) {
-      const float4* nd = sc.nodes + 4 * (size_t)cur;
+  bool hit = false;
+  while (cur != kTraversalDone) {
+    while (cur >= 0) {
+      const float4* nd = g.nodes + 4 * (size_t)cur;
       float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
       float tn0, tn1;
       bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, o, inv, tfar, tn0);
@@ -244,41 +293,45 @@ __device__ __forceinline__ bool mesh_any(const SceneDev& sc, f3 o, f3 d, float t
         stk[sp * stride] = c1;
         sp++;
         cur = c0;
-        continue;
-      }
-      if (h0) {
+      } else if (h0) {
         cur = c0;
-        continue;
-      }
-      if (h1) {
+      } else if (h1) {
         cur = c1;
-        continue;
+      } else if (sp == 0) {
+        cur = kTraversalDone;
+      } else {
+        sp--;
+        cur = stk[sp * stride];
       }
-    } else {
+    }
+    while (cur < 0 && cur != kTraversalDone) {
       uint32_t v = ~(uint32_t)cur;
       uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
       for (uint32_t k = 0; k < cnt; k++) {
         uint32_t slot = first + k;
-        float4 A = sc.tri0[slot], B = sc.tri1[slot], C = sc.tri2[slot];
+        float4 A = g.tri0[slot], B = g.tri1[slot], C = g.tri2[slot];
         float t = tri_intersect(mk3(A.x, A.y, A.z), mk3(B.x, B.y, B.z), mk3(C.x, C.y, C.z), o, d);
-        if (eps < t && t < tfar) return true;
+        if (eps < t && t < tfar) hit = true;
+      }
+      if (hit || sp == 0) {
+        cur = kTraversalDone;
+      } else {
+        sp--;
+        cur = stk[sp * stride];
       }
     }
-    if (sp == 0) break;
-    sp--;
-    cur = stk[sp * stride];
   }
-  return false;
+  return hit;
 }
 
 // Scene::castRay, reference Scene.h:144-189: mesh first, then the spheres in
 // order (the first of equal t wins); the sphere wins only when strictly closer
 // than the mesh hit.  Returns t and an id: kMiss, kSphereBit|index, or triangle slot.
-__device__ __forceinline__ void cast_ray(const SceneDev& sc, f3 o, f3 d, int* stk, int stride,
-                                         float& t_out, uint32_t& id_out) {
+__device__ __forceinline__ void cast_ray(const SceneDev& sc, const Geom& g, f3 o, f3 d, int* stk,
+                                         int stride, float& t_out, uint32_t& id_out) {
   float tfar;
   uint32_t slot;
-  mesh_closest(sc, o, d, stk, stride, tfar, slot);
+  mesh_closest(sc, g, o, d, stk, stride, tfar, slot);
   float ts = INFINITY;
   uint32_t si = 0;
   for (uint32_t i = 0; i < sc.num_spheres; i++) {
@@ -300,14 +353,14 @@ __device__ __forceinline__ void cast_ray(const SceneDev& sc, f3 o, f3 d, int* st
 
 // Scene::isOccluded, reference Scene.h:191-225, for a segment whose far end
 // tfar = distance - eps has been computed by the caller (distance >= 2 eps).
-__device__ __forceinline__ bool occluded(const SceneDev& sc, f3 o, f3 d, float tfar, int* stk,
-                                         int stride) {
+__device__ __forceinline__ bool occluded(const SceneDev& sc, const Geom& g, f3 o, f3 d, float tfar,
+                                         int* stk, int stride) {
   for (uint32_t i = 0; i < sc.num_spheres; i++) {
     float4 s = sc.sph0[i];
     float t = sphere_intersect(mk3(s.x, s.y, s.z), s.w, o, d, sc.eps);
     if (t > sc.eps && t < tfar) return true;
   }
-  return mesh_any(sc, o, d, tfar, stk, stride);
+  return mesh_any(sc, g, o, d, tfar, stk, stride);
 }
 
 // Surface normal and material of a hit (reference Scene.h:169-171,181-187;
@@ -739,10 +792,20 @@ __global__ __launch_bounds__(256) void k_generate(Queue q, const SegCounter* seg
   store_path(q, s * rp.cap + seg[s].gen_slot0 + j, use_depth != 0, p);
 }
 
-template <int BLOCK>
+// Dynamic LDS of the traversal kernels: the per-lane stacks (stack_entries x
+// BLOCK ints), then, when LDS_SCENE, the staged BVH and triangles.
+#define RTX_TRACE_PROLOGUE()                                                          \
+  extern __shared__ float4 lds_dyn[];                                                 \
+  int* const stk = reinterpret_cast<int*>(lds_dyn) + threadIdx.x;                     \
+  const Geom geom = LDS_SCENE ? stage_geom_lds(sc, lds_dyn + (stack_entries * BLOCK) / 4, \
+                                               threadIdx.x, BLOCK)                    \
+                              : global_geom(sc)
+
+template <int BLOCK, bool LDS_SCENE>
 __global__ __launch_bounds__(BLOCK) void k_intersect(SceneDev sc, Queue q, uint2* hits,
-                                                     const SegCounter* seg, int qi, uint32_t cap) {
-  extern __shared__ int lds_stack[];
+                                                     const SegCounter* seg, int qi, uint32_t cap,
+                                                     int stack_entries) {
+  RTX_TRACE_PROLOGUE();
   const uint32_t s = blockIdx.y;
   const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
   if (j >= seg_paths(seg[s].c[qi])) return;
@@ -751,7 +814,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(SceneDev sc, Queue q, uint2
   float2 b = q.r1[i];
   float t;
   uint32_t id;
-  cast_ray(sc, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), lds_stack + threadIdx.x, BLOCK, t, id);
+  cast_ray(sc, geom, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), stk, BLOCK, t, id);
   hits[i] = make_uint2(__float_as_uint(t), id);
 }
 
@@ -789,10 +852,11 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, Queue in, Queue out,
 
 // Traces the NEE segments queued by k_shade; an unoccluded one adds its
 // contribution to the colour of the path it belongs to (Integrator.h:217-223).
-template <int BLOCK>
+template <int BLOCK, bool LDS_SCENE>
 __global__ __launch_bounds__(BLOCK) void k_shadow(SceneDev sc, Queue paths, ShadowQueue sq,
-                                                  const SegCounter* seg, int q_out, uint32_t cap) {
-  extern __shared__ int lds_stack[];
+                                                  const SegCounter* seg, int q_out, uint32_t cap,
+                                                  int stack_entries) {
+  RTX_TRACE_PROLOGUE();
   const uint32_t s = blockIdx.y;
   const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
   if (j >= seg_shadow(seg[s].c[q_out])) return;
@@ -801,7 +865,7 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(SceneDev sc, Queue paths, Shad
   float4 b = sq.q1[k];
   const uint32_t slot = __float_as_uint(b.w);
   float4 r0 = paths.r0[slot];
-  bool occ = occluded(sc, mk3(r0.x, r0.y, r0.z), mk3(a.x, a.y, a.z), a.w, lds_stack + threadIdx.x, BLOCK);
+  bool occ = occluded(sc, geom, mk3(r0.x, r0.y, r0.z), mk3(a.x, a.y, a.z), a.w, stk, BLOCK);
   if (!occ) {
     float4 s1 = paths.s1[slot];
     s1.x += b.x;
@@ -816,10 +880,11 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(SceneDev sc, Queue paths, Shad
 // kernels is all launch latency.  Every lane leaves after at most kFinishCap
 // bounces (a path that long has probability below 0.99^65536).
 constexpr uint32_t kFinishCap = 65536;
-template <int BLOCK>
+template <int BLOCK, bool LDS_SCENE>
 __global__ __launch_bounds__(BLOCK) void k_finish(SceneDev sc, Queue q, const SegCounter* seg, int qi,
-                                                  uint32_t cap, float* res, Summary* sum) {
-  extern __shared__ int lds_stack[];
+                                                  uint32_t cap, float* res, Summary* sum,
+                                                  int stack_entries) {
+  RTX_TRACE_PROLOGUE();
   const uint32_t s = blockIdx.y;
   const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
   const bool active = j < seg_paths(seg[s].c[qi]);
@@ -827,11 +892,10 @@ __global__ __launch_bounds__(BLOCK) void k_finish(SceneDev sc, Queue q, const Se
   if (active) {
     PathState p;
     load_path(q, s * cap + j, sc.max_bounces != 0, p);
-    int* stk = lds_stack + threadIdx.x;
     for (uint32_t it = 0; it < kFinishCap; it++) {
       float t;
       uint32_t id;
-      cast_ray(sc, p.o, p.d, stk, BLOCK, t, id);
+      cast_ray(sc, geom, p.o, p.d, stk, BLOCK, t, id);
       nb++;
       bool want_shadow, did_nee;
       ShadowReq sr;
@@ -839,7 +903,7 @@ __global__ __launch_bounds__(BLOCK) void k_finish(SceneDev sc, Queue q, const Se
       nn += did_nee ? 1u : 0u;
       if (want_shadow) {
         ns++;
-        if (!occluded(sc, p.o, sr.d, sr.tfar, stk, BLOCK)) p.col = vadd(p.col, sr.contrib);
+        if (!occluded(sc, geom, p.o, sr.d, sr.tfar, stk, BLOCK)) p.col = vadd(p.col, sr.contrib);
       }
       if (!alive) break;
     }
@@ -874,18 +938,18 @@ __global__ __launch_bounds__(256) void k_reduce(const float* res, float* accum, 
 // ----------------------------------------------------------------------------
 // Fixed-ray-set kernels (parity entry points).
 
-template <int BLOCK>
+template <int BLOCK, bool LDS_SCENE>
 __global__ __launch_bounds__(BLOCK) void k_trace_closest(SceneDev sc, const float* rays, uint32_t n,
                                                          uint32_t* kind, uint32_t* prim, float* t_out,
-                                                         float* normal) {
-  extern __shared__ int lds_stack[];
+                                                         float* normal, int stack_entries) {
+  RTX_TRACE_PROLOGUE();
   uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   f3 o = mk3(rays[6 * (size_t)i], rays[6 * (size_t)i + 1], rays[6 * (size_t)i + 2]);
   f3 d = mk3(rays[6 * (size_t)i + 3], rays[6 * (size_t)i + 4], rays[6 * (size_t)i + 5]);
   float t;
   uint32_t id;
-  cast_ray(sc, o, d, lds_stack + threadIdx.x, BLOCK, t, id);
+  cast_ray(sc, geom, o, d, stk, BLOCK, t, id);
   f3 n3 = mk3(0, 0, 0);
   if (id == kMiss) {
     kind[i] = 0;
@@ -911,10 +975,11 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest(SceneDev sc, const floa
   }
 }
 
-template <int BLOCK>
+template <int BLOCK, bool LDS_SCENE>
 __global__ __launch_bounds__(BLOCK) void k_trace_occluded(SceneDev sc, const float* rays,
-                                                          const float* dist, uint32_t n, uint8_t* out) {
-  extern __shared__ int lds_stack[];
+                                                          const float* dist, uint32_t n, uint8_t* out,
+                                                          int stack_entries) {
+  RTX_TRACE_PROLOGUE();
   uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
   f3 o = mk3(rays[6 * (size_t)i], rays[6 * (size_t)i + 1], rays[6 * (size_t)i + 2]);
@@ -922,7 +987,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_occluded(SceneDev sc, const flo
   float distance = dist[i];
   bool occ = false;
   if (!(distance < 2.0f * sc.eps))  // Scene.h:192-194
-    occ = occluded(sc, o, d, distance - sc.eps, lds_stack + threadIdx.x, BLOCK);
+    occ = occluded(sc, geom, o, d, distance - sc.eps, stk, BLOCK);
   out[i] = occ ? 1 : 0;
 }
 

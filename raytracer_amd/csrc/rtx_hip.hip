@@ -44,6 +44,7 @@ constexpr uint32_t kDefaultResultMiB = 8192;     // per-sample result buffer bud
 constexpr uint32_t kSegmentTarget = 8192;        // aim for this many slots per queue segment
 constexpr uint32_t kMaxSegments = 512;
 constexpr int kTraceBlock = 128;                 // threads per block of the traversal kernels
+constexpr size_t kLdsSceneMaxBytes = 16 * 1024;  // stage BVH + triangles in LDS up to this size
 constexpr int kFinishBlock = 64;
 constexpr int kPollSlots = 4;
 
@@ -91,6 +92,8 @@ struct rtx_ctx {
   rtx::SceneDev scene{};
   rtx_scene_info info{};
   int stack_entries = 8;
+  bool lds_scene = false;   // BVH + triangles small enough to be staged in LDS by every block
+  size_t lds_scene_bytes = 0;
 
   // path pool
   DevBuf<float4> r0[2], s0[2], s1[2], sq0, sq1;
@@ -276,8 +279,11 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
   if (!g.ok) return fail(RTX_ERR_HIP, "rtx_set_scene: hipSetDevice failed");
 
   auto t_begin = std::chrono::steady_clock::now();
+  // Small scenes are staged in LDS by every block and get 2-triangle leaves; with
+  // those a scene of n triangles has about n/2 inner nodes of 64 bytes.
+  const bool small_scene = s->num_triangles > 0 && s->num_triangles * (48 + 32 + 8) <= kLdsSceneMaxBytes;
   rtx::FlatBvh bvh;
-  rtx::build_bvh(s->triangles, s->num_triangles, bvh);
+  rtx::build_bvh(s->triangles, s->num_triangles, small_scene ? 2u : 4u, bvh);
   int stack_entries = pick_stack_entries(bvh.max_depth);
   if (stack_entries < 0) return fail(RTX_ERR_UNSUPPORTED, "rtx_set_scene: BVH too deep");
 
@@ -364,6 +370,8 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
   d.max_bounces = c->cfg.max_bounces;
   d.integrator = c->cfg.integrator;
   c->stack_entries = stack_entries;
+  c->lds_scene_bytes = (nodes.size() + 3 * nt) * sizeof(float4);
+  c->lds_scene = nt > 0 && c->lds_scene_bytes <= kLdsSceneMaxBytes;
   c->have_scene = true;
   c->info.num_nodes = d.num_nodes;
   c->info.num_triangles = d.num_tris;
@@ -432,8 +440,10 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
   rtx::Summary* sum = c->sum.p;
   rtx::ShadowQueue sq{c->sq0.p, c->sq1.p};
   const int use_depth = c->cfg.max_bounces ? 1 : 0;
-  const size_t lds = (size_t)c->stack_entries * kTraceBlock * sizeof(int);
-  const size_t lds_fin = (size_t)c->stack_entries * kFinishBlock * sizeof(int);
+  const size_t scene_lds = c->lds_scene ? c->lds_scene_bytes : 0;
+  const size_t lds = (size_t)c->stack_entries * kTraceBlock * sizeof(int) + scene_lds;
+  const size_t lds_fin = (size_t)c->stack_entries * kFinishBlock * sizeof(int) + scene_lds;
+  const int se = c->stack_entries;
   const bool shadows = c->scene.num_lights != 0 && c->cfg.integrator == 0;
   LaunchTimer lt(c, st, timer);
   uint64_t launches = 0, iterations = 0;
@@ -468,8 +478,12 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
     if (left_upper == 0 && active_upper == 0) break;
     if (left_upper == 0 && active_upper <= c->finish_paths) {
       lt.begin(kFinish, active_upper);
-      rtx::k_finish<kFinishBlock><<<dim3(div_up(seg_max_upper, kFinishBlock), nseg), kFinishBlock, lds_fin, st>>>(
-          c->scene, queue_of(c, cur), seg, cur, cap, c->res.p, sum);
+      if (c->lds_scene)
+        rtx::k_finish<kFinishBlock, true><<<dim3(div_up(seg_max_upper, kFinishBlock), nseg), kFinishBlock, lds_fin, st>>>(
+            c->scene, queue_of(c, cur), seg, cur, cap, c->res.p, sum, se);
+      else
+        rtx::k_finish<kFinishBlock, false><<<dim3(div_up(seg_max_upper, kFinishBlock), nseg), kFinishBlock, lds_fin, st>>>(
+            c->scene, queue_of(c, cur), seg, cur, cap, c->res.p, sum, se);
       lt.end();
       launches++;
       finished = true;
@@ -479,7 +493,10 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
     Queue qc = queue_of(c, cur), qn = queue_of(c, nxt);
     const uint32_t gx128 = div_up(seg_max_upper, kTraceBlock), gx256 = div_up(seg_max_upper, 256);
     lt.begin(kIsect, active_upper);
-    rtx::k_intersect<kTraceBlock><<<dim3(gx128, nseg), kTraceBlock, lds, st>>>(c->scene, qc, c->hits.p, seg, cur, cap);
+    if (c->lds_scene)
+      rtx::k_intersect<kTraceBlock, true><<<dim3(gx128, nseg), kTraceBlock, lds, st>>>(c->scene, qc, c->hits.p, seg, cur, cap, se);
+    else
+      rtx::k_intersect<kTraceBlock, false><<<dim3(gx128, nseg), kTraceBlock, lds, st>>>(c->scene, qc, c->hits.p, seg, cur, cap, se);
     lt.end();
     lt.begin(kShade, active_upper);
     rtx::k_shade<<<dim3(gx256, nseg), 256, 0, st>>>(c->scene, qc, qn, sq, c->hits.p, seg, cur, cap, c->res.p);
@@ -487,7 +504,10 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
     launches += 2;
     if (shadows) {
       lt.begin(kShadow, active_upper);
-      rtx::k_shadow<kTraceBlock><<<dim3(gx128, nseg), kTraceBlock, lds, st>>>(c->scene, qn, sq, seg, nxt, cap);
+      if (c->lds_scene)
+        rtx::k_shadow<kTraceBlock, true><<<dim3(gx128, nseg), kTraceBlock, lds, st>>>(c->scene, qn, sq, seg, nxt, cap, se);
+      else
+        rtx::k_shadow<kTraceBlock, false><<<dim3(gx128, nseg), kTraceBlock, lds, st>>>(c->scene, qn, sq, seg, nxt, cap, se);
       lt.end();
       launches++;
     }
@@ -687,9 +707,13 @@ int rtx_trace_closest(rtx_ctx* c, const float* rays_host, size_t n, uint32_t* ki
     TRY_BREAK(prim.alloc(n));
     if (normal_out) TRY_BREAK(nrm.alloc(n * 3));
     TRY_BREAK(hipMemcpy(rays.p, rays_host, n * 6 * sizeof(float), hipMemcpyHostToDevice));
-    size_t lds = (size_t)c->stack_entries * kTraceBlock * sizeof(int);
-    rtx::k_trace_closest<kTraceBlock><<<div_up((uint32_t)n, kTraceBlock), kTraceBlock, lds, 0>>>(
-        c->scene, rays.p, (uint32_t)n, kind.p, prim.p, t.p, nrm.p);
+    size_t lds = (size_t)c->stack_entries * kTraceBlock * sizeof(int) + (c->lds_scene ? c->lds_scene_bytes : 0);
+    if (c->lds_scene)
+      rtx::k_trace_closest<kTraceBlock, true><<<div_up((uint32_t)n, kTraceBlock), kTraceBlock, lds, 0>>>(
+          c->scene, rays.p, (uint32_t)n, kind.p, prim.p, t.p, nrm.p, c->stack_entries);
+    else
+      rtx::k_trace_closest<kTraceBlock, false><<<div_up((uint32_t)n, kTraceBlock), kTraceBlock, lds, 0>>>(
+          c->scene, rays.p, (uint32_t)n, kind.p, prim.p, t.p, nrm.p, c->stack_entries);
     TRY_BREAK(hipGetLastError());
     TRY_BREAK(hipDeviceSynchronize());
     TRY_BREAK(hipMemcpy(kind_out, kind.p, n * 4, hipMemcpyDeviceToHost));
@@ -719,9 +743,13 @@ int rtx_trace_occluded(rtx_ctx* c, const float* rays_host, const float* distance
     TRY_BREAK(occ.alloc(n));
     TRY_BREAK(hipMemcpy(rays.p, rays_host, n * 6 * sizeof(float), hipMemcpyHostToDevice));
     TRY_BREAK(hipMemcpy(dist.p, distance_host, n * sizeof(float), hipMemcpyHostToDevice));
-    size_t lds = (size_t)c->stack_entries * kTraceBlock * sizeof(int);
-    rtx::k_trace_occluded<kTraceBlock><<<div_up((uint32_t)n, kTraceBlock), kTraceBlock, lds, 0>>>(
-        c->scene, rays.p, dist.p, (uint32_t)n, occ.p);
+    size_t lds = (size_t)c->stack_entries * kTraceBlock * sizeof(int) + (c->lds_scene ? c->lds_scene_bytes : 0);
+    if (c->lds_scene)
+      rtx::k_trace_occluded<kTraceBlock, true><<<div_up((uint32_t)n, kTraceBlock), kTraceBlock, lds, 0>>>(
+          c->scene, rays.p, dist.p, (uint32_t)n, occ.p, c->stack_entries);
+    else
+      rtx::k_trace_occluded<kTraceBlock, false><<<div_up((uint32_t)n, kTraceBlock), kTraceBlock, lds, 0>>>(
+          c->scene, rays.p, dist.p, (uint32_t)n, occ.p, c->stack_entries);
     TRY_BREAK(hipGetLastError());
     TRY_BREAK(hipDeviceSynchronize());
     TRY_BREAK(hipMemcpy(occluded_out, occ.p, n, hipMemcpyDeviceToHost));

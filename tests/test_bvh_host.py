@@ -22,21 +22,21 @@ def probe(tmp_path_factory):
                            os.path.join(ROOT, "tests", "native", "bvh_probe.cpp"),
                            os.path.join(src, "bvh_build.cpp"), "-o", str(out)])
     lib = C.CDLL(str(out))
-    lib.bvh_probe.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.bvh_probe.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
     return lib
 
 
-def build(probe, tris):
+def build(probe, tris, max_leaf=4):
     tris = np.ascontiguousarray(tris, np.float32).reshape(-1, 9)
-    n = probe.bvh_probe(tris.ctypes.data, len(tris), None, None, None)
+    n = probe.bvh_probe(tris.ctypes.data, len(tris), max_leaf, None, None, None)
     nodes = np.zeros((n, 16), np.float32)
     order = np.zeros(len(tris), np.uint32)
     depth = C.c_uint32()
-    probe.bvh_probe(tris.ctypes.data, len(tris), nodes.ctypes.data, order.ctypes.data, C.byref(depth))
+    probe.bvh_probe(tris.ctypes.data, len(tris), max_leaf, nodes.ctypes.data, order.ctypes.data, C.byref(depth))
     return nodes, order, depth.value
 
 
-def walk(nodes, order, tris):
+def walk(nodes, order, tris, max_leaf=4):
     """Returns (leaf ranges seen, max depth); asserts box containment."""
     seen = np.zeros(len(order), np.int32)
     maxd = 0
@@ -59,7 +59,7 @@ def walk(nodes, order, tris):
             else:
                 v = ~int(c)
                 first, cnt = v >> 3, (v & 7) + 1
-                assert cnt <= 4 and first + cnt <= len(order)
+                assert cnt <= max_leaf and first + cnt <= len(order)
                 seen[first:first + cnt] += 1
                 pts = tris[order[first:first + cnt]].reshape(-1, 3)
                 assert np.all(pts >= np.array(lo)) and np.all(pts <= np.array(hi))
@@ -72,11 +72,12 @@ def walk(nodes, order, tris):
     ("one", lambda: scenes.cornell().triangles[:1]), ("three", lambda: scenes.cornell().triangles[:3]),
     ("degenerate", lambda: np.tile(scenes.cornell().triangles[:1], (37, 1))),
 ])
-def test_flat_bvh_structure(name, make, probe):
+@pytest.mark.parametrize("max_leaf", [1, 2, 4])
+def test_flat_bvh_structure(name, make, max_leaf, probe):
     tris = make()
-    nodes, order, depth = build(probe, tris)
+    nodes, order, depth = build(probe, tris, max_leaf)
     assert sorted(order.tolist()) == list(range(len(tris)))
-    seen, maxd = walk(nodes, order, tris)
+    seen, maxd = walk(nodes, order, tris, max_leaf)
     if len(tris) > 1:
         assert np.all(seen == 1), "every triangle is in exactly one leaf"
     else:
@@ -85,7 +86,7 @@ def test_flat_bvh_structure(name, make, probe):
 
 
 def test_empty_mesh_has_no_nodes(probe):
-    assert probe.bvh_probe(None, 0, None, None, None) == 0
+    assert probe.bvh_probe(None, 0, 4, None, None, None) == 0
 
 
 def test_flat_bvh_walk_equals_linear_scan(probe, oracle):
