@@ -219,7 +219,7 @@ def main():
                                    (" per GPU (disjoint sample ranges, RCCL reduce)" if world > 1 and not args.strong else ""),
                        "triangles": int(info.num_triangles), "spheres": int(info.num_spheres),
                        "lights": int(info.num_lights), "bvh_nodes": int(info.num_nodes),
-                       "pool_paths": int(args.pool) or (1 << 22)},
+                       "pool_paths": int(args.pool) or (1 << 23)},
             "time_to_image_ms": round(elapsed / args.steps * 1e3, 3),
             "mpaths_per_s": round(paths / elapsed / 1e6, 2),
             "bounces_per_path": round(bounces / max(paths, 1), 3),

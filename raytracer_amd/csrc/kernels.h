@@ -491,12 +491,21 @@ struct ShadowReq {
   float tfar;
 };
 
-__device__ __forceinline__ void load_path(const Queue& q, uint32_t i, bool use_depth, PathState& p) {
+// `fresh`: the path was written by k_generate and has not bounced yet.  Its
+// attenuation (1), colour (0), mis_brdf_pdf (-1) and nee_pdf are the constants
+// pathTrace starts with (Integrator.h:99-106); k_generate does not write them
+// and they are not read back (32 of the 64 bytes, on the most numerous paths).
+__device__ __forceinline__ void load_path(const Queue& q, uint32_t i, bool use_depth, bool fresh,
+                                          PathState& p) {
   float4 r0 = q.r0[i];
   float2 r1 = q.r1[i];
-  float4 s0 = q.s0[i];
-  float4 s1 = q.s1[i];
   uint2 s2 = q.s2[i];
+  float4 s0 = make_float4(1.0f, 1.0f, 1.0f, -1.0f);
+  float4 s1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (!fresh) {
+    s0 = q.s0[i];
+    s1 = q.s1[i];
+  }
   p.o = mk3(r0.x, r0.y, r0.z);
   p.d = mk3(r0.w, r1.x, r1.y);
   p.att = mk3(s0.x, s0.y, s0.z);
@@ -779,17 +788,13 @@ __global__ __launch_bounds__(256) void k_generate(Queue q, const SegCounter* seg
     }
   }
   o = vadd(o, mk3(cam.offx, cam.offy, cam.offz));
-  PathState p;
-  p.o = o;
-  p.d = d;
-  p.att = splat3(1.0f);
-  p.col = splat3(0.0f);
-  p.mis_pdf = -1.0f;
-  p.nee_pdf = 0.0f;
-  p.ordinal = ordinal;
-  p.rng = rng;
-  p.depth = 0;
-  store_path(q, s * rp.cap + seg[s].gen_slot0 + j, use_depth != 0, p);
+  // A fresh path: only the ray, the sample ordinal and the generator are stored
+  // (see load_path).
+  const uint32_t slot = s * rp.cap + seg[s].gen_slot0 + j;
+  q.r0[slot] = make_float4(o.x, o.y, o.z, d.x);
+  q.r1[slot] = make_float2(d.y, d.z);
+  q.s2[slot] = make_uint2(ordinal, rng);
+  if (use_depth) q.depth[slot] = 0;
 }
 
 // Dynamic LDS of the traversal kernels: the per-lane stacks (stack_entries x
@@ -835,7 +840,7 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, Queue in, Queue out,
   ShadowReq sr;
   bool alive = false, want_shadow = false, did_nee = false;
   if (active) {
-    load_path(in, i, use_depth, p);
+    load_path(in, i, use_depth, j >= seg[s].gen_slot0, p);
     uint2 h = hits[i];
     alive = shade_bounce(sc, p, __uint_as_float(h.x), h.y, want_shadow, did_nee, sr);
     if (!alive) store_result(res, p.ordinal, p.col);
@@ -891,7 +896,7 @@ __global__ __launch_bounds__(BLOCK) void k_finish(SceneDev sc, Queue q, const Se
   uint32_t nb = 0, nn = 0, ns = 0;
   if (active) {
     PathState p;
-    load_path(q, s * cap + j, sc.max_bounces != 0, p);
+    load_path(q, s * cap + j, sc.max_bounces != 0, j >= seg[s].gen_slot0, p);
     for (uint32_t it = 0; it < kFinishCap; it++) {
       float t;
       uint32_t id;
