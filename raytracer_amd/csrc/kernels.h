@@ -366,7 +366,7 @@ __device__ __forceinline__ bool occluded(const SceneDev& sc, const Geom& g, f3 o
 // Surface normal and material of a hit (reference Scene.h:169-171,181-187;
 // Sphere::normal Obj.h:269-271).  The mesh normal is normalize(Ng) with
 // Ng = (b-a)x(c-a), not flipped towards the ray.
-__device__ __forceinline__ void hit_surface(const SceneDev& sc, uint32_t id, f3 o, f3 d, float t,
+__device__ __forceinline__ void hit_surface(const SceneDev& sc, const Geom& g, uint32_t id, f3 o, f3 d, float t,
                                             f3& n, f3& albedo, float& emission, int& surface) {
   if (id & kSphereBit) {
     uint32_t i = id & ~kSphereBit;
@@ -378,7 +378,7 @@ __device__ __forceinline__ void hit_surface(const SceneDev& sc, uint32_t id, f3 
     emission = m.w;
     surface = sc.sph2[i];
   } else {
-    float4 B = sc.tri1[id], C = sc.tri2[id];
+    float4 B = g.tri1[id], C = g.tri2[id];
     n = vnormalized(vcross(mk3(B.x, B.y, B.z), mk3(C.x, C.y, C.z)));
     uint32_t mi = __float_as_uint(B.w);
     float4 m = sc.mat0[mi];
@@ -529,8 +529,8 @@ __device__ __forceinline__ void store_path(const Queue& q, uint32_t i, bool use_
 // closest hit (t, id) is known.  Returns true when the path goes on (p then holds
 // the next ray); `want_shadow` asks for the NEE segment in `sr` to be tested for
 // occlusion before its contribution is added to the path's colour.
-__device__ __forceinline__ bool shade_bounce(const SceneDev& sc, PathState& p, float t, uint32_t id,
-                                             bool& want_shadow, bool& did_nee, ShadowReq& sr) {
+__device__ __forceinline__ bool shade_bounce(const SceneDev& sc, const Geom& g, PathState& p, float t,
+                                             uint32_t id, bool& want_shadow, bool& did_nee, ShadowReq& sr) {
   want_shadow = false;
   did_nee = false;
   if (sc.max_bounces) p.depth++;
@@ -544,7 +544,7 @@ __device__ __forceinline__ bool shade_bounce(const SceneDev& sc, PathState& p, f
   f3 n3, albedo;
   float emis;
   int surface;
-  hit_surface(sc, id, p.o, p.d, t, n3, albedo, emis, surface);
+  hit_surface(sc, g, id, p.o, p.d, t, n3, albedo, emis, surface);
   if (sc.integrator == 1) {  // rayTraceNormals, Integrator.h:87-96
     p.col = vadd(vscale(n3, 0.5f), splat3(0.5f));
     return false;
@@ -842,7 +842,7 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, Queue in, Queue out,
   if (active) {
     load_path(in, i, use_depth, j >= seg[s].gen_slot0, p);
     uint2 h = hits[i];
-    alive = shade_bounce(sc, p, __uint_as_float(h.x), h.y, want_shadow, did_nee, sr);
+    alive = shade_bounce(sc, global_geom(sc), p, __uint_as_float(h.x), h.y, want_shadow, did_nee, sr);
     if (!alive) store_result(res, p.ordinal, p.col);
   }
   uint32_t pos, spos;
@@ -904,7 +904,7 @@ __global__ __launch_bounds__(BLOCK) void k_finish(SceneDev sc, Queue q, const Se
       nb++;
       bool want_shadow, did_nee;
       ShadowReq sr;
-      bool alive = shade_bounce(sc, p, t, id, want_shadow, did_nee, sr);
+      bool alive = shade_bounce(sc, geom, p, t, id, want_shadow, did_nee, sr);
       nn += did_nee ? 1u : 0u;
       if (want_shadow) {
         ns++;
@@ -932,6 +932,25 @@ __global__ __launch_bounds__(BLOCK) void k_finish(SceneDev sc, Queue q, const Se
 // f runs over the 3*band_pixels floats of the band; accum points at the band.
 __global__ __launch_bounds__(256) void k_reduce(const float* res, float* accum, uint32_t nfloats,
                                                 uint32_t spp_chunk) {
+  // Four floats per lane (16-byte loads) when the band allows it; the additions
+  // of one float stay in sample order either way.
+  if ((nfloats & 3u) == 0) {
+    const uint32_t n4 = nfloats >> 2;
+    uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n4) return;
+    float4 acc = reinterpret_cast<const float4*>(accum)[f];
+    const float4* src = reinterpret_cast<const float4*>(res) + f;
+#pragma unroll 8
+    for (uint32_t s = 0; s < spp_chunk; s++) {
+      float4 v = src[(size_t)s * n4];
+      acc.x += v.x;
+      acc.y += v.y;
+      acc.z += v.z;
+      acc.w += v.w;
+    }
+    reinterpret_cast<float4*>(accum)[f] = acc;
+    return;
+  }
   uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= nfloats) return;
   float acc = accum[f];
@@ -963,7 +982,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest(SceneDev sc, const floa
     f3 albedo;
     float emis;
     int surface;
-    hit_surface(sc, id, o, d, t, n3, albedo, emis, surface);
+    hit_surface(sc, geom, id, o, d, t, n3, albedo, emis, surface);
     if (id & kSphereBit) {
       kind[i] = 2;
       prim[i] = id & ~kSphereBit;
