@@ -1,0 +1,130 @@
+// main.cpp -- a headless driver in the shape of the reference's Raytracer.cpp main():
+// build the scene (buildScene, Raytracer.cpp:150-230), then the progressive loop of
+// render_loop (Raytracer.cpp:307-331), saving the image instead of showing a window.
+//
+//   rt_host [--obj FILE] [--width W] [--height H] [--spp N] [--passes P] [--sky]
+//           [--out PREFIX] [--parse-only]
+//
+// Without --obj the live scene's roles are built procedurally (the reference's
+// geometry/CornellBox-Original.obj is not part of its repository): red/green/white walls,
+// a 2-triangle light of emission 10 and the glass sphere of Raytracer.cpp:174-175.
+// With --obj, material slots are overridden the way Raytracer.cpp:163-171 does when the
+// file has at least 8 materials.
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+
+#include "rt_host.hpp"
+
+using namespace rt;
+
+static void quad(Mesh* m, Vec3 p0, Vec3 p1, Vec3 p2, Vec3 p3, unsigned mat) {
+  m->add_triangle(Triangle{p0, p1, p2}, mat);
+  m->add_triangle(Triangle{p0, p2, p3}, mat);
+}
+
+static Mesh* procedural_cornell() {
+  Mesh* m = new Mesh();
+  for (int i = 0; i < 8; i++) m->add_material(Material{Vec3(0.65f, 0.05f, 0.05f), 0.0f, diffuse});
+  quad(m, {-1, 0, 1}, {-1, 0, -1}, {-1, 2, -1}, {-1, 2, 1}, 0);   // left
+  quad(m, {1, 0, -1}, {1, 0, 1}, {1, 2, 1}, {1, 2, -1}, 1);       // right
+  quad(m, {-1, 0, 1}, {1, 0, 1}, {1, 0, -1}, {-1, 0, -1}, 2);     // floor
+  quad(m, {-1, 2, -1}, {1, 2, -1}, {1, 2, 1}, {-1, 2, 1}, 3);     // ceiling
+  quad(m, {-1, 0, -1}, {1, 0, -1}, {1, 2, -1}, {-1, 2, -1}, 4);   // back
+  quad(m, {-0.25f, 1.98f, -0.25f}, {0.25f, 1.98f, -0.25f}, {0.25f, 1.98f, 0.25f}, {-0.25f, 1.98f, 0.25f}, 7);
+  return m;
+}
+
+int main(int argc, char** argv) {
+  std::string obj, out = "render";
+  uint32_t width = 800, height = 800, spp = 16, passes = 1;
+  bool sky = false, parse_only = false;
+  for (int i = 1; i < argc; i++) {
+    auto next = [&](const char* name) -> const char* {
+      if (i + 1 >= argc) {
+        std::cerr << name << " needs a value\n";
+        std::exit(2);
+      }
+      return argv[++i];
+    };
+    if (!std::strcmp(argv[i], "--obj")) obj = next("--obj");
+    else if (!std::strcmp(argv[i], "--width")) width = (uint32_t)std::atoi(next("--width"));
+    else if (!std::strcmp(argv[i], "--height")) height = (uint32_t)std::atoi(next("--height"));
+    else if (!std::strcmp(argv[i], "--spp")) spp = (uint32_t)std::atoi(next("--spp"));
+    else if (!std::strcmp(argv[i], "--passes")) passes = (uint32_t)std::atoi(next("--passes"));
+    else if (!std::strcmp(argv[i], "--out")) out = next("--out");
+    else if (!std::strcmp(argv[i], "--sky")) sky = true;
+    else if (!std::strcmp(argv[i], "--parse-only")) parse_only = true;
+    else {
+      std::cerr << "unknown argument " << argv[i] << "\n";
+      return 2;
+    }
+  }
+  try {
+    if (parse_only) {
+      // OBJ front end only (no device needed): prints what load_mesh produced.
+      if (obj.empty()) throw Error("--parse-only needs --obj");
+      Mesh* m = load_obj(obj);
+      std::printf("triangles %zu materials %zu\n", m->triangles.size(), m->materials.size());
+      for (size_t i = 0; i < m->triangles.size(); i++) {
+        const Triangle& t = m->triangles[i];
+        std::printf("%u %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g %.9g\n", m->material_idxs[i], t.a.x, t.a.y, t.a.z,
+                    t.b.x, t.b.y, t.b.z, t.c.x, t.c.y, t.c.z);
+      }
+      delete m;
+      return 0;
+    }
+    rtx_config cfg = default_config(width, height);
+    cfg.sky = sky ? 1 : 0;
+
+    auto t1 = std::chrono::high_resolution_clock::now();
+    Scene scene(cfg);
+    Mesh* mesh = obj.empty() ? procedural_cornell() : scene.load_mesh(obj);
+    // buildScene's overrides (Raytracer.cpp:151-171)
+    Material diffuseMat{Vec3(0.93f, 0.93f, 0.93f), 0.0f, diffuse};
+    Material redMat{Vec3(0.55f, 0.09f, 0.09f), 0.0f, diffuse};
+    Material greenMat{Vec3(0.16f, 0.55f, 0.15f), 0.0f, diffuse};
+    Material specularMat{Vec3(1.0f), 0.0f, specular};
+    if (mesh->materials.size() >= 8) {
+      mesh->materials[0] = redMat;
+      mesh->materials[1] = greenMat;
+      for (int k = 2; k <= 6; k++) mesh->materials[k] = diffuseMat;
+      mesh->materials[7].emission = 10.0f;
+    } else {
+      for (Material& m : mesh->materials) m = diffuseMat;
+    }
+    scene.addMesh(mesh);
+    scene.spheres.push_back(Sphere(Vec3(-0.5f, 0.302f, 0.55f), 0.3f));
+    scene.spheres[0].material = specularMat;
+    scene.commit();
+    float seconds = std::chrono::duration<float>(std::chrono::high_resolution_clock::now() - t1).count();
+    std::printf("Scene built in %f seconds (%zu triangles, %zu materials)\n", seconds, mesh->triangles.size(),
+                mesh->materials.size());
+
+    Img img(width, height);
+    clear(img, scene);
+    auto t0 = std::chrono::high_resolution_clock::now();
+    for (uint32_t p = 0; p < passes; p++) {
+      auto tp = std::chrono::high_resolution_clock::now();
+      render(img, scene, spp);
+      float s = std::chrono::duration<float>(std::chrono::high_resolution_clock::now() - tp).count();
+      // the reference's per-pass report (Raytracer.cpp:281-285, 322-323)
+      std::printf("Took %f seconds\nCast %llu rays\n%f samples per second \n", s,
+                  (unsigned long long)spp * width * height, (double)spp * width * height / s);
+      float total = std::chrono::duration<float>(std::chrono::high_resolution_clock::now() - t0).count();
+      std::printf("Accumulated %u samples per pixel over %f seconds\n\n", img.sample_count, total);
+    }
+    rtx_stats st;
+    check(rtx_get_stats(scene.ctx(), &st), "rtx_get_stats");
+    std::printf("paths %llu, path-bounces %llu, shadow rays %llu\n", (unsigned long long)st.paths,
+                (unsigned long long)st.bounces, (unsigned long long)st.shadow_rays);
+    if (!img.savePFM((out + ".pfm").c_str()) || !img.savePPM((out + ".ppm").c_str()))
+      throw Error("cannot write " + out + ".pfm/.ppm");
+    std::printf("Saved %s.pfm and %s.ppm\n", out.c_str(), out.c_str());
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "error: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}
