@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--strong", action="store_true", help="split the workload's spp across ranks instead")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + RTX_BENCH_SAME_GPU=1 rehearses the N>1 logic on one GPU (buffers are summed "
+                         "through host memory); the real run uses nccl = RCCL")
     args = ap.parse_args()
 
     import torch
@@ -114,9 +117,14 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the renderer has no CPU path")
+    if os.environ.get("RTX_BENCH_SAME_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     from raytracer_amd.capi import Config, Renderer
 
@@ -141,7 +149,13 @@ def main():
         accum.zero_()
         r.render(accum, spp, sample_base=base, seed=0x5EED, stream=stream)
         if world > 1:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+            if args.backend == "nccl":
+                dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+            else:
+                host = accum.cpu()
+                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+                if rank == 0:
+                    accum.copy_(host)
 
     def fence():
         if world > 1:
@@ -160,7 +174,8 @@ def main():
     st = r.stats()
 
     tvals = torch.tensor([elapsed, float(st.bounces), float(st.paths), float(st.shadow_rays),
-                          float(st.nee_samples)], dtype=torch.float64, device="cuda")
+                          float(st.nee_samples)], dtype=torch.float64,
+                         device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
         tmax = tvals.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -810,17 +810,39 @@ template <int BLOCK, bool LDS_SCENE>
 __global__ __launch_bounds__(BLOCK) void k_intersect(SceneDev sc, Queue q, uint2* hits,
                                                      const SegCounter* seg, int qi, uint32_t cap,
                                                      int stack_entries) {
-  RTX_TRACE_PROLOGUE();
   const uint32_t s = blockIdx.y;
-  const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
-  if (j >= seg_paths(seg[s].c[qi])) return;
-  const uint32_t i = s * cap + j;
-  float4 a = q.r0[i];
-  float2 b = q.r1[i];
-  float t;
-  uint32_t id;
-  cast_ray(sc, geom, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), stk, BLOCK, t, id);
-  hits[i] = make_uint2(__float_as_uint(t), id);
+  const uint32_t n = seg_paths(seg[s].c[qi]);
+  if (blockIdx.x * BLOCK >= n) return;  // the whole block is beyond the fill: skip the staging too
+  RTX_TRACE_PROLOGUE();
+  // Block-stride loop over the segment: a block that staged the scene in LDS
+  // amortises that over several batches of rays.
+  // The next batch's ray is loaded before the current one is traced, so the HBM
+  // latency of the load hides behind the traversal.
+  const uint32_t stride = gridDim.x * BLOCK;
+  uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+  float4 a = make_float4(0, 0, 0, 0);
+  float2 b = make_float2(0, 0);
+  if (j < n) {
+    a = q.r0[s * cap + j];
+    b = q.r1[s * cap + j];
+  }
+  while (j < n) {
+    const uint32_t i = s * cap + j;
+    const uint32_t jn = j + stride;
+    float4 an = a;
+    float2 bn = b;
+    if (jn < n) {
+      an = q.r0[s * cap + jn];
+      bn = q.r1[s * cap + jn];
+    }
+    float t;
+    uint32_t id;
+    cast_ray(sc, geom, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), stk, BLOCK, t, id);
+    hits[i] = make_uint2(__float_as_uint(t), id);
+    a = an;
+    b = bn;
+    j = jn;
+  }
 }
 
 // One bounce for every path of queue `qi`; survivors are appended to the same
@@ -861,22 +883,24 @@ template <int BLOCK, bool LDS_SCENE>
 __global__ __launch_bounds__(BLOCK) void k_shadow(SceneDev sc, Queue paths, ShadowQueue sq,
                                                   const SegCounter* seg, int q_out, uint32_t cap,
                                                   int stack_entries) {
-  RTX_TRACE_PROLOGUE();
   const uint32_t s = blockIdx.y;
-  const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
-  if (j >= seg_shadow(seg[s].c[q_out])) return;
-  const uint32_t k = s * cap + j;
-  float4 a = sq.q0[k];
-  float4 b = sq.q1[k];
-  const uint32_t slot = __float_as_uint(b.w);
-  float4 r0 = paths.r0[slot];
-  bool occ = occluded(sc, geom, mk3(r0.x, r0.y, r0.z), mk3(a.x, a.y, a.z), a.w, stk, BLOCK);
-  if (!occ) {
-    float4 s1 = paths.s1[slot];
-    s1.x += b.x;
-    s1.y += b.y;
-    s1.z += b.z;
-    paths.s1[slot] = s1;
+  const uint32_t n = seg_shadow(seg[s].c[q_out]);
+  if (blockIdx.x * BLOCK >= n) return;
+  RTX_TRACE_PROLOGUE();
+  for (uint32_t j = blockIdx.x * BLOCK + threadIdx.x; j < n; j += gridDim.x * BLOCK) {
+    const uint32_t k = s * cap + j;
+    float4 a = sq.q0[k];
+    float4 b = sq.q1[k];
+    const uint32_t slot = __float_as_uint(b.w);
+    float4 r0 = paths.r0[slot];
+    bool occ = occluded(sc, geom, mk3(r0.x, r0.y, r0.z), mk3(a.x, a.y, a.z), a.w, stk, BLOCK);
+    if (!occ) {
+      float4 s1 = paths.s1[slot];
+      s1.x += b.x;
+      s1.y += b.y;
+      s1.z += b.z;
+      paths.s1[slot] = s1;
+    }
   }
 }
 

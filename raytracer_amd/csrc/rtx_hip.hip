@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -46,6 +47,7 @@ constexpr uint32_t kMaxSegments = 512;
 constexpr int kTraceBlock = 128;                 // threads per block of the traversal kernels
 constexpr size_t kLdsSceneMaxBytes = 16 * 1024;  // stage BVH + triangles in LDS up to this size
 constexpr int kFinishBlock = 64;
+constexpr uint32_t kTraceBatches = 2;  // ray batches per block of k_intersect/k_shadow (the next batch's loads overlap the current traversal)
 constexpr int kPollSlots = 4;
 
 template <typename T>
@@ -491,7 +493,10 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
     }
     const int nxt = cur ^ 1;
     Queue qc = queue_of(c, cur), qn = queue_of(c, nxt);
-    const uint32_t gx128 = div_up(seg_max_upper, kTraceBlock), gx256 = div_up(seg_max_upper, 256);
+    // Traversal kernels loop over their segment, kTraceBatches batches of rays per block.
+    uint32_t gx128 = div_up(seg_max_upper, kTraceBlock);
+    gx128 = std::max(1u, std::min(gx128, div_up(gx128, kTraceBatches)));
+    const uint32_t gx256 = div_up(seg_max_upper, 256);
     lt.begin(kIsect, active_upper);
     if (c->lds_scene)
       rtx::k_intersect<kTraceBlock, true><<<dim3(gx128, nseg), kTraceBlock, lds, st>>>(c->scene, qc, c->hits.p, seg, cur, cap, se);
