@@ -62,6 +62,22 @@ typedef struct {
   rtx_material material;
 } rtx_sphere;
 
+/* Axis-aligned box, the reference's commented-out class Box (Obj.h:35-93). */
+typedef struct {
+  float min[3];
+  float max[3];
+  rtx_material material;
+} rtx_box;
+
+/* Plane through `point` with normal `normal`: the reference's scenes construct
+ * `new Plane(point, normal)` (Raytracer.cpp:184-221) but the class itself is not in its
+ * repository; t = ((point - o).n)/(d.n) and the surface normal is `normal` as given. */
+typedef struct {
+  float point[3];
+  float normal[3];
+  rtx_material material;
+} rtx_plane;
+
 /* The reference's compile-time constants as run-time fields:
  * WIDTH/HEIGHT/EPS/NEE_EMISSION_THRESHOLD globals.h:3-8, MAX_BOUNCE_PROB
  * Integrator.h:12, camera type and fov Raytracer.cpp:145-147, camera origin
@@ -102,6 +118,13 @@ typedef struct {
   size_t num_materials;
   const rtx_sphere* spheres; /* Scene::spheres, Scene.h:37; may be NULL when num_spheres==0 */
   size_t num_spheres;
+  /* Analytic boxes and planes.  castRay tests them after the spheres, by the rule it applies
+   * to spheres (Scene.h:165-177): t > EPS, the first of equal t wins, and an analytic object
+   * beats the mesh only when strictly closer.  Like spheres they are never sampled as lights. */
+  const rtx_box* boxes;
+  size_t num_boxes;
+  const rtx_plane* planes;
+  size_t num_planes;
 } rtx_scene;
 
 typedef struct {
@@ -164,8 +187,8 @@ int rtx_resolve(rtx_ctx* ctx, const float* accum_dev, uint32_t total_spp, float*
 /* Fixed-ray-set entry points (parity tests and tools).
  * rays_host: n*6 floats (o, d); d is used as given (not normalised), as
  * Scene::castRay does (Scene.h:144-189).  Outputs are host arrays of n elements
- * (normal_out: n*3, may be NULL): kind 0 miss / 1 triangle / 2 sphere; prim =
- * triangle index as passed to rtx_set_scene, or sphere index; t = hit distance
+ * (normal_out: n*3, may be NULL): kind 0 miss / 1 triangle / 2 sphere / 3 box / 4 plane; prim =
+ * triangle index as passed to rtx_set_scene, or the index in its own array; t = hit distance
  * (+inf on a miss).  Synchronous. */
 int rtx_trace_closest(rtx_ctx* ctx, const float* rays_host, size_t n, uint32_t* kind_out,
                       uint32_t* prim_out, float* t_out, float* normal_out);

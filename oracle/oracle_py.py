@@ -26,6 +26,14 @@ class OSphere(C.Structure):
     _fields_ = [("c", C.c_float * 3), ("r", C.c_float), ("material", OMaterial)]
 
 
+class OBox(C.Structure):
+    _fields_ = [("min", C.c_float * 3), ("max", C.c_float * 3), ("material", OMaterial)]
+
+
+class OPlane(C.Structure):
+    _fields_ = [("point", C.c_float * 3), ("normal", C.c_float * 3), ("material", OMaterial)]
+
+
 class OConfig(C.Structure):
     _fields_ = [
         ("width", C.c_uint32), ("height", C.c_uint32), ("fov", C.c_float),
@@ -79,7 +87,12 @@ def lib() -> C.CDLL:
         L.orc_camera_ray.argtypes = [C.POINTER(OConfig), C.c_float, C.c_float, C.POINTER(u32), vp, vp]
         L.orc_img_update.argtypes = [vp, u32, vp]
         L.orc_scene_create.restype = vp
-        L.orc_scene_create.argtypes = [vp, sz, vp, vp, sz, vp, sz, C.POINTER(OConfig)]
+        L.orc_scene_create.argtypes = [vp, sz, vp, vp, sz, vp, sz, vp, sz, vp, sz, C.POINTER(OConfig)]
+        L.orc_box_intersect.restype = C.c_float
+        L.orc_box_intersect.argtypes = [vp] * 4
+        L.orc_box_normal.argtypes = [vp] * 4
+        L.orc_plane_intersect.restype = C.c_float
+        L.orc_plane_intersect.argtypes = [vp] * 4
         L.orc_scene_destroy.argtypes = [vp]
         L.orc_scene_destroy.restype = None
         L.orc_scene_num_lights.restype = sz
@@ -173,6 +186,20 @@ def sphere_intersect(c, r, o, d) -> float:
     return float(lib().orc_sphere_intersect(_p(_f3(c)), r, _p(_f3(o)), _p(_f3(d))))
 
 
+def box_intersect(mn, mx, o, d) -> float:
+    return float(lib().orc_box_intersect(_p(_f3(mn)), _p(_f3(mx)), _p(_f3(o)), _p(_f3(d))))
+
+
+def box_normal(mn, mx, p) -> np.ndarray:
+    out = np.empty(3, np.float32)
+    lib().orc_box_normal(_p(_f3(mn)), _p(_f3(mx)), _p(_f3(p)), _p(out))
+    return out
+
+
+def plane_intersect(point, normal, o, d) -> float:
+    return float(lib().orc_plane_intersect(_p(_f3(point)), _p(_f3(normal)), _p(_f3(o)), _p(_f3(d))))
+
+
 def triangle_sample_point(a, b, c, state: int):
     st = C.c_uint32(state)
     p = np.empty(3, np.float32)
@@ -204,13 +231,16 @@ class OracleScene:
     def __init__(self, scene, cfg):
         self.cfg = cfg
         self._oc = config_from(cfg)
-        self._keep = (scene.triangles, scene.material_index, scene.materials, scene.spheres)
+        boxes = getattr(scene, "boxes", np.zeros(0))
+        planes = getattr(scene, "planes", np.zeros(0))
+        self._keep = (scene.triangles, scene.material_index, scene.materials, scene.spheres, boxes, planes)
         L = lib()
         self._h = L.orc_scene_create(_p(scene.triangles), scene.triangles.shape[0],
                                      _p(scene.material_index), _p(scene.materials),
                                      scene.materials.shape[0],
-                                     _p(scene.spheres) if len(scene.spheres) else None,
-                                     len(scene.spheres), C.byref(self._oc))
+                                     _p(scene.spheres) if len(scene.spheres) else None, len(scene.spheres),
+                                     _p(boxes) if len(boxes) else None, len(boxes),
+                                     _p(planes) if len(planes) else None, len(planes), C.byref(self._oc))
         if not self._h:
             raise ValueError("orc_scene_create failed (material index out of range?)")
 

@@ -188,6 +188,37 @@ inline float sphere_intersect(V3 c, float r, V3 o, V3 d, float eps) {
   float t1 = (-B - disc) / 2.0f;
   return t1 > eps ? t1 : (-B + disc) / 2.0f;
 }
+// Box::intersect, the reference's commented-out class (Obj.h:43-68).
+inline float box_intersect(V3 mn, V3 mx, V3 o, V3 d, float eps) {
+  float t1 = (mn.x - o.x) / d.x;
+  float t2 = (mx.x - o.x) / d.x;
+  float tmin = std::min(t1, t2);
+  float tmax = std::max(t1, t2);
+  t1 = (mn.y - o.y) / d.y;
+  t2 = (mx.y - o.y) / d.y;
+  tmin = std::max(tmin, std::min(t1, t2));
+  tmax = std::min(tmax, std::max(t1, t2));
+  t1 = (mn.z - o.z) / d.z;
+  t2 = (mx.z - o.z) / d.z;
+  tmin = std::max(tmin, std::min(t1, t2));
+  tmax = std::min(tmax, std::max(t1, t2));
+  return tmax >= tmin ? (tmin > eps ? tmin : tmax) : kInf;
+}
+// sgn, Obj.h:21-23; Box::normal, Obj.h:70-87.
+inline float sgn(float x) { return (float)((x > 0) - (x < 0)); }
+inline V3 box_normal(V3 mn, V3 mx, V3 p) {
+  V3 c = divs(add(mx, mn), 2.0f);
+  V3 v = sub(p, c);
+  const float cv[3] = {v.x, v.y, v.z};
+  const float lo[3] = {mn.x, mn.y, mn.z}, hi[3] = {mx.x, mx.y, mx.z};
+  int am = 0;
+  for (int i = 1; i < 3; i++)
+    if (std::fabs(cv[i]) * (hi[am] - lo[am]) > std::fabs(cv[am]) * (hi[i] - lo[i])) am = i;
+  return mk((am == 0) * sgn(v.x), (am == 1) * sgn(v.y), (am == 2) * sgn(v.z));
+}
+// Plane(point, normal): build-defined (the reference has call sites only).
+inline float plane_intersect(V3 pt, V3 n, V3 o, V3 d) { return dot(sub(pt, o), n) / dot(d, n); }
+
 // A light = Triangle copy made in Scene::commit (Scene.h:129-141) through the
 // Triangle ctor (Obj.h:107): n = normalize((b-a)x(c-b)), rcp_area = 2/|(b-a)x(c-b)|.
 struct Light {
@@ -321,6 +352,8 @@ struct Scene {
   std::vector<uint32_t> mat_idx;
   std::vector<orc_material> mats;
   std::vector<orc_sphere> spheres;
+  std::vector<orc_box> boxes;
+  std::vector<orc_plane> planes;
   std::vector<Light> lights;
   Bvh bvh;
 };
@@ -435,6 +468,29 @@ inline void cast_ray(const Scene& S, V3 o, V3 d, bool use_bvh, Hit& h) {
       h.n = divs(sub(add(o, scale(d, t)), ld(sp.c)), sp.r);  // Sphere::normal, Obj.h:269-271
     }
   }
+  // Boxes, then planes, continue the object list by the same rule.
+  for (size_t i = 0; i < S.boxes.size(); i++) {
+    const orc_box& b = S.boxes[i];
+    float t = box_intersect(ld(b.min), ld(b.max), o, d, S.cfg.eps);
+    if (t > S.cfg.eps && t < h.t) {
+      h.t = t;
+      h.kind = 3;
+      h.prim = (uint32_t)i;
+      h.mat = b.material;
+      h.n = box_normal(ld(b.min), ld(b.max), add(o, scale(d, t)));
+    }
+  }
+  for (size_t i = 0; i < S.planes.size(); i++) {
+    const orc_plane& pl = S.planes[i];
+    float t = plane_intersect(ld(pl.point), ld(pl.normal), o, d);
+    if (t > S.cfg.eps && t < h.t) {
+      h.t = t;
+      h.kind = 4;
+      h.prim = (uint32_t)i;
+      h.mat = pl.material;
+      h.n = ld(pl.normal);
+    }
+  }
   if (h.t < tfar) return;  // Scene.h:175-177: the sphere wins only when strictly closer
   if (prim != 0xffffffffu) {  // Scene.h:181-187
     const Tri& T = S.tris[prim];
@@ -454,6 +510,14 @@ inline bool is_occluded(const Scene& S, V3 o, V3 d, float distance, bool use_bvh
   for (size_t i = 0; i < S.spheres.size(); i++) {
     const orc_sphere& sp = S.spheres[i];
     float t = sphere_intersect(ld(sp.c), sp.r, o, d, eps);
+    if (t > eps && t < distance - eps) return true;
+  }
+  for (size_t i = 0; i < S.boxes.size(); i++) {
+    float t = box_intersect(ld(S.boxes[i].min), ld(S.boxes[i].max), o, d, eps);
+    if (t > eps && t < distance - eps) return true;
+  }
+  for (size_t i = 0; i < S.planes.size(); i++) {
+    float t = plane_intersect(ld(S.planes[i].point), ld(S.planes[i].normal), o, d);
     if (t > eps && t < distance - eps) return true;
   }
   return use_bvh ? mesh_any_bvh(S, o, d, distance - eps) : mesh_any_linear(S, o, d, distance - eps);
@@ -680,6 +744,15 @@ float orc_triangle_intersect(const float a[3], const float b[3], const float c[3
 float orc_sphere_intersect(const float c[3], float r, const float o[3], const float d[3]) {
   return sphere_intersect(ld(c), r, ld(o), ld(d), 1.0e-3f);
 }
+float orc_box_intersect(const float mn[3], const float mx[3], const float o[3], const float d[3]) {
+  return box_intersect(ld(mn), ld(mx), ld(o), ld(d), 1.0e-3f);
+}
+void orc_box_normal(const float mn[3], const float mx[3], const float p[3], float n_out[3]) {
+  st(n_out, box_normal(ld(mn), ld(mx), ld(p)));
+}
+float orc_plane_intersect(const float point[3], const float normal[3], const float o[3], const float d[3]) {
+  return plane_intersect(ld(point), ld(normal), ld(o), ld(d));
+}
 float orc_triangle_sample_point(const float a[3], const float b[3], const float c[3],
                                 uint32_t* rng_state, float p_out[3], float n_out[3]) {
   Tri t{ld(a), ld(b), ld(c)};
@@ -708,7 +781,8 @@ void orc_img_update(float pixel[3], uint32_t sample_count, const float color[3])
 
 orc_scene* orc_scene_create(const float* tris, size_t ntri, const uint32_t* mat_idx,
                             const orc_material* mats, size_t nmat, const orc_sphere* spheres,
-                            size_t nsph, const orc_config* cfg) {
+                            size_t nsph, const orc_box* boxes, size_t nbox, const orc_plane* planes,
+                            size_t nplane, const orc_config* cfg) {
   orc_scene* h = new orc_scene();
   Scene& S = h->s;
   S.cfg = *cfg;
@@ -716,6 +790,8 @@ orc_scene* orc_scene_create(const float* tris, size_t ntri, const uint32_t* mat_
   S.mat_idx.assign(mat_idx, mat_idx + ntri);
   S.mats.assign(mats, mats + nmat);
   if (nsph) S.spheres.assign(spheres, spheres + nsph);
+  if (nbox) S.boxes.assign(boxes, boxes + nbox);
+  if (nplane) S.planes.assign(planes, planes + nplane);
   for (size_t i = 0; i < ntri; i++) {
     S.tris[i] = Tri{ld(tris + 9 * i), ld(tris + 9 * i + 3), ld(tris + 9 * i + 6)};
     if (S.mat_idx[i] >= nmat) {

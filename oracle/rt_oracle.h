@@ -48,6 +48,21 @@ typedef struct {
   orc_material material;
 } orc_sphere;
 
+/* The commented-out class Box (Obj.h:35-93). */
+typedef struct {
+  float min[3];
+  float max[3];
+  orc_material material;
+} orc_box;
+
+/* Plane(point, normal): only call sites exist in the reference (Raytracer.cpp:184-221);
+ * t = ((point - o).n)/(d.n), surface normal = `normal` as given.  Build-defined. */
+typedef struct {
+  float point[3];
+  float normal[3];
+  orc_material material;
+} orc_plane;
+
 /* Compile-time constants of the reference turned into fields
  * (globals.h:3-8, Integrator.h:12, Raytracer.cpp:145, Camera.h:23,37-39,64-65). */
 typedef struct {
@@ -91,6 +106,9 @@ void orc_sky_emission(const float d[3], float out[3]);
 float orc_triangle_intersect(const float a[3], const float b[3], const float c[3],
                              const float o[3], const float d[3]);
 float orc_sphere_intersect(const float c[3], float r, const float o[3], const float d[3]);
+float orc_box_intersect(const float mn[3], const float mx[3], const float o[3], const float d[3]);
+void orc_box_normal(const float mn[3], const float mx[3], const float p[3], float n_out[3]);
+float orc_plane_intersect(const float point[3], const float normal[3], const float o[3], const float d[3]);
 /* Triangle ctor + samplePoint: returns rcp_area; writes the point and n. */
 float orc_triangle_sample_point(const float a[3], const float b[3], const float c[3],
                                 uint32_t* rng_state, float p_out[3], float n_out[3]);
@@ -103,11 +121,12 @@ void orc_img_update(float pixel[3], uint32_t sample_count, const float color[3])
 /* tris: ntri*9 floats (a,b,c), prim id = index (Obj.h:218-226 order). */
 orc_scene* orc_scene_create(const float* tris, size_t ntri, const uint32_t* mat_idx,
                             const orc_material* mats, size_t nmat,
-                            const orc_sphere* spheres, size_t nsph, const orc_config* cfg);
+                            const orc_sphere* spheres, size_t nsph, const orc_box* boxes, size_t nbox,
+                            const orc_plane* planes, size_t nplane, const orc_config* cfg);
 void orc_scene_destroy(orc_scene*);
 size_t orc_scene_num_lights(const orc_scene*);
 
-/* kind: 0 miss, 1 triangle, 2 sphere. prim: triangle index / sphere index.
+/* kind: 0 miss, 1 triangle, 2 sphere, 3 box, 4 plane. prim: index in its own array.
  * use_bvh = 0 runs the first-party linear scan (Obj.h:184-195), 1 the oracle's BVH. */
 void orc_trace_closest(const orc_scene*, const float* rays /* n*6 */, size_t n, int use_bvh,
                        uint32_t* kind, uint32_t* prim, float* t, float* normal /* n*3 or NULL */);

@@ -34,6 +34,14 @@ class Sphere(C.Structure):
     _fields_ = [("c", C.c_float * 3), ("r", C.c_float), ("material", Material)]
 
 
+class Box(C.Structure):
+    _fields_ = [("min", C.c_float * 3), ("max", C.c_float * 3), ("material", Material)]
+
+
+class Plane(C.Structure):
+    _fields_ = [("point", C.c_float * 3), ("normal", C.c_float * 3), ("material", Material)]
+
+
 class CConfig(C.Structure):
     _fields_ = [
         ("width", C.c_uint32), ("height", C.c_uint32), ("fov", C.c_float),
@@ -53,6 +61,8 @@ class CScene(C.Structure):
         ("material_index", C.POINTER(C.c_uint32)),
         ("materials", C.POINTER(Material)), ("num_materials", C.c_size_t),
         ("spheres", C.POINTER(Sphere)), ("num_spheres", C.c_size_t),
+        ("boxes", C.POINTER(Box)), ("num_boxes", C.c_size_t),
+        ("planes", C.POINTER(Plane)), ("num_planes", C.c_size_t),
     ]
 
 
@@ -162,6 +172,9 @@ class Config:
 
 MATERIAL_DTYPE = np.dtype([("albedo", "<f4", 3), ("emission", "<f4"), ("surface", "<i4")])
 SPHERE_DTYPE = np.dtype([("c", "<f4", 3), ("r", "<f4"), ("material", MATERIAL_DTYPE)])
+BOX_DTYPE = np.dtype([("min", "<f4", 3), ("max", "<f4", 3), ("material", MATERIAL_DTYPE)])
+PLANE_DTYPE = np.dtype([("point", "<f4", 3), ("normal", "<f4", 3), ("material", MATERIAL_DTYPE)])
+assert BOX_DTYPE.itemsize == C.sizeof(Box) == 44 and PLANE_DTYPE.itemsize == C.sizeof(Plane) == 44
 assert MATERIAL_DTYPE.itemsize == C.sizeof(Material) == 20
 assert SPHERE_DTYPE.itemsize == C.sizeof(Sphere) == 36
 
@@ -174,12 +187,16 @@ class SceneData:
     materials: np.ndarray            # (m,) MATERIAL_DTYPE
     spheres: np.ndarray = field(default_factory=lambda: np.zeros(0, SPHERE_DTYPE))
     name: str = ""
+    boxes: np.ndarray = field(default_factory=lambda: np.zeros(0, BOX_DTYPE))
+    planes: np.ndarray = field(default_factory=lambda: np.zeros(0, PLANE_DTYPE))
 
     def __post_init__(self):
         self.triangles = np.ascontiguousarray(self.triangles, dtype=np.float32).reshape(-1, 9)
         self.material_index = np.ascontiguousarray(self.material_index, dtype=np.uint32)
         self.materials = np.ascontiguousarray(self.materials, dtype=MATERIAL_DTYPE)
         self.spheres = np.ascontiguousarray(self.spheres, dtype=SPHERE_DTYPE)
+        self.boxes = np.ascontiguousarray(self.boxes, dtype=BOX_DTYPE)
+        self.planes = np.ascontiguousarray(self.planes, dtype=PLANE_DTYPE)
         assert self.triangles.shape[0] == self.material_index.shape[0]
 
 
@@ -240,6 +257,10 @@ class Renderer:
         cs.num_materials = s.materials.shape[0]
         cs.spheres = s.spheres.ctypes.data_as(C.POINTER(Sphere)) if len(s.spheres) else None
         cs.num_spheres = len(s.spheres)
+        cs.boxes = s.boxes.ctypes.data_as(C.POINTER(Box)) if len(s.boxes) else None
+        cs.num_boxes = len(s.boxes)
+        cs.planes = s.planes.ctypes.data_as(C.POINTER(Plane)) if len(s.planes) else None
+        cs.num_planes = len(s.planes)
         self._check(self.lib.rtx_set_scene(self._ctx, C.byref(cs)))
         return self.scene_info()
 

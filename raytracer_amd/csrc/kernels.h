@@ -55,14 +55,20 @@ struct SceneDev {
   const float4* tri2;    //                    (c-a, 0)
   const float4* mat0;    // per material: (albedo.rgb, emission)
   const int* mat1;       //               surface
+  // Analytic objects, in the order spheres, boxes, planes; object i of that
+  // combined list has material (sph1[i], sph2[i]).
   const float4* sph0;    // per sphere: (c.xyz, r)
-  const float4* sph1;    //             (albedo.rgb, emission)
-  const int* sph2;       //             surface
+  const float4* sph1;    // per analytic object: (albedo.rgb, emission)
+  const int* sph2;       //                      surface
+  const float4* box0;    // per box: (min.xyz, 0)
+  const float4* box1;    //          (max.xyz, 0)
+  const float4* pln0;    // per plane: (point.xyz, 0)
+  const float4* pln1;    //            (normal.xyz, 0)
   const float4* light0;  // per light: (a.xyz, rcp_area)
   const float4* light1;  //            (b.xyz, emission)
   const float4* light2;  //            (c.xyz, 0)
   const float4* light3;  //            (n.xyz, 0)
-  uint32_t num_nodes, num_tris, num_spheres, num_lights;
+  uint32_t num_nodes, num_tris, num_spheres, num_boxes, num_planes, num_lights;
   float eps, nee_threshold, rr_cap;
   int sky;
   uint32_t max_bounces;
@@ -189,6 +195,43 @@ __device__ __forceinline__ float sphere_intersect(f3 c, float r, f3 o, f3 d, flo
   float disc = sqrtf(disc2);
   float t1 = (-B - disc) / 2.0f;
   return t1 > eps ? t1 : (-B + disc) / 2.0f;
+}
+
+// Box::intersect, the axis-aligned box of the reference's commented-out class
+// (Obj.h:43-68): per-axis divisions, std::min/std::max folds,
+// tmax >= tmin ? (tmin > EPS ? tmin : tmax) : INFINITY.
+__device__ __forceinline__ float box_intersect(f3 mn, f3 mx, f3 o, f3 d, float eps) {
+  float t1 = (mn.x - o.x) / d.x;
+  float t2 = (mx.x - o.x) / d.x;
+  float tmin = std_min(t1, t2);
+  float tmax = std_max(t1, t2);
+  t1 = (mn.y - o.y) / d.y;
+  t2 = (mx.y - o.y) / d.y;
+  tmin = std_max(tmin, std_min(t1, t2));
+  tmax = std_min(tmax, std_max(t1, t2));
+  t1 = (mn.z - o.z) / d.z;
+  t2 = (mx.z - o.z) / d.z;
+  tmin = std_max(tmin, std_min(t1, t2));
+  tmax = std_min(tmax, std_max(t1, t2));
+  return tmax >= tmin ? (tmin > eps ? tmin : tmax) : INFINITY;
+}
+// Box::normal (Obj.h:70-87): the face whose axis has the largest |p - centre|
+// relative to the box's extent on that axis; sgn() of Obj.h:21-23.
+__device__ __forceinline__ float sgnf(float x) { return (float)((x > 0) - (x < 0)); }
+__device__ __forceinline__ f3 box_normal(f3 mn, f3 mx, f3 p) {
+  f3 c = vdivs(vadd(mx, mn), 2.0f);
+  f3 v = vsub(p, c);
+  const float cv[3] = {v.x, v.y, v.z};
+  const float ext[3] = {mx.x - mn.x, mx.y - mn.y, mx.z - mn.z};
+  int am = 0;
+  for (int i = 1; i < 3; i++)
+    if (fabsf(cv[i]) * ext[am] > fabsf(cv[am]) * ext[i]) am = i;
+  return mk3((float)(am == 0) * sgnf(v.x), (float)(am == 1) * sgnf(v.y), (float)(am == 2) * sgnf(v.z));
+}
+// Plane(point, normal): the reference only has call sites (Raytracer.cpp:184-221), no
+// class; this is the build's definition: t = ((point - o) . n) / (d . n), normal = n as given.
+__device__ __forceinline__ float plane_intersect(f3 pt, f3 n, f3 o, f3 d) {
+  return vdot(vsub(pt, o), n) / vdot(d, n);
 }
 
 // Slab test of one child box against [0, tmax].  fminf/fmaxf drop a NaN operand
@@ -342,6 +385,23 @@ __device__ __forceinline__ void cast_ray(const SceneDev& sc, const Geom& g, f3 o
       si = i;
     }
   }
+  // Boxes and planes continue the same list (same rule: t > EPS, first of equal t wins).
+  for (uint32_t i = 0; i < sc.num_boxes; i++) {
+    float4 a = sc.box0[i], b = sc.box1[i];
+    float t = box_intersect(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), o, d, sc.eps);
+    if (t > sc.eps && t < ts) {
+      ts = t;
+      si = sc.num_spheres + i;
+    }
+  }
+  for (uint32_t i = 0; i < sc.num_planes; i++) {
+    float4 a = sc.pln0[i], b = sc.pln1[i];
+    float t = plane_intersect(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), o, d);
+    if (t > sc.eps && t < ts) {
+      ts = t;
+      si = sc.num_spheres + sc.num_boxes + i;
+    }
+  }
   if (ts < tfar) {
     t_out = ts;
     id_out = kSphereBit | si;
@@ -360,6 +420,16 @@ __device__ __forceinline__ bool occluded(const SceneDev& sc, const Geom& g, f3 o
     float t = sphere_intersect(mk3(s.x, s.y, s.z), s.w, o, d, sc.eps);
     if (t > sc.eps && t < tfar) return true;
   }
+  for (uint32_t i = 0; i < sc.num_boxes; i++) {
+    float4 a = sc.box0[i], b = sc.box1[i];
+    float t = box_intersect(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), o, d, sc.eps);
+    if (t > sc.eps && t < tfar) return true;
+  }
+  for (uint32_t i = 0; i < sc.num_planes; i++) {
+    float4 a = sc.pln0[i], b = sc.pln1[i];
+    float t = plane_intersect(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), o, d);
+    if (t > sc.eps && t < tfar) return true;
+  }
   return mesh_any(sc, g, o, d, tfar, stk, stride);
 }
 
@@ -370,10 +440,18 @@ __device__ __forceinline__ void hit_surface(const SceneDev& sc, const Geom& g, u
                                             f3& n, f3& albedo, float& emission, int& surface) {
   if (id & kSphereBit) {
     uint32_t i = id & ~kSphereBit;
-    float4 s = sc.sph0[i];
     float4 m = sc.sph1[i];
     f3 p = vadd(o, vscale(d, t));
-    n = vdivs(vsub(p, mk3(s.x, s.y, s.z)), s.w);
+    if (i < sc.num_spheres) {
+      float4 s = sc.sph0[i];
+      n = vdivs(vsub(p, mk3(s.x, s.y, s.z)), s.w);
+    } else if (i < sc.num_spheres + sc.num_boxes) {
+      float4 a = sc.box0[i - sc.num_spheres], b = sc.box1[i - sc.num_spheres];
+      n = box_normal(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), p);
+    } else {
+      float4 b = sc.pln1[i - sc.num_spheres - sc.num_boxes];
+      n = mk3(b.x, b.y, b.z);
+    }
     albedo = mk3(m.x, m.y, m.z);
     emission = m.w;
     surface = sc.sph2[i];
@@ -1008,8 +1086,17 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest(SceneDev sc, const floa
     int surface;
     hit_surface(sc, geom, id, o, d, t, n3, albedo, emis, surface);
     if (id & kSphereBit) {
-      kind[i] = 2;
-      prim[i] = id & ~kSphereBit;
+      uint32_t k = id & ~kSphereBit;
+      if (k < sc.num_spheres) {
+        kind[i] = 2;
+      } else if (k < sc.num_spheres + sc.num_boxes) {
+        kind[i] = 3;
+        k -= sc.num_spheres;
+      } else {
+        kind[i] = 4;
+        k -= sc.num_spheres + sc.num_boxes;
+      }
+      prim[i] = k;
     } else {
       kind[i] = 1;
       prim[i] = __float_as_uint(sc.tri0[id].w);

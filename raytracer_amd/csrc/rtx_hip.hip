@@ -89,7 +89,7 @@ struct rtx_ctx {
 
   // scene
   bool have_scene = false;
-  DevBuf<float4> nodes, tri0, tri1, tri2, mat0, sph0, sph1, light0, light1, light2, light3;
+  DevBuf<float4> nodes, tri0, tri1, tri2, mat0, sph0, sph1, box0, box1, pln0, pln1, light0, light1, light2, light3;
   DevBuf<int> mat1, sph2;
   rtx::SceneDev scene{};
   rtx_scene_info info{};
@@ -155,6 +155,7 @@ void free_ctx(rtx_ctx* c) {
   DeviceGuard g(c->device);
   c->nodes.release(); c->tri0.release(); c->tri1.release(); c->tri2.release();
   c->mat0.release(); c->mat1.release(); c->sph0.release(); c->sph1.release(); c->sph2.release();
+  c->box0.release(); c->box1.release(); c->pln0.release(); c->pln1.release();
   c->light0.release(); c->light1.release(); c->light2.release(); c->light3.release();
   for (int i = 0; i < 2; i++) {
     c->r0[i].release(); c->r1[i].release(); c->s0[i].release(); c->s1[i].release();
@@ -270,10 +271,12 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
   if (!c || !s) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_set_scene: null argument");
   if (s->num_triangles && (!s->triangles || !s->material_index || !s->materials))
     return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_set_scene: null geometry arrays");
-  if (s->num_spheres && !s->spheres) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_set_scene: null spheres");
+  if ((s->num_spheres && !s->spheres) || (s->num_boxes && !s->boxes) || (s->num_planes && !s->planes))
+    return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_set_scene: null analytic-object array");
   if (s->num_triangles >= (1u << 28))
     return fail(RTX_ERR_UNSUPPORTED, "rtx_set_scene: at most 2^28-1 triangles");
-  if (s->num_spheres >= (1u << 20)) return fail(RTX_ERR_UNSUPPORTED, "rtx_set_scene: too many spheres");
+  if (s->num_spheres + s->num_boxes + s->num_planes >= (1u << 20))
+    return fail(RTX_ERR_UNSUPPORTED, "rtx_set_scene: too many analytic objects");
   for (size_t i = 0; i < s->num_triangles; i++)
     if (s->material_index[i] >= s->num_materials)
       return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_set_scene: material index out of range");
@@ -314,14 +317,31 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
     m0[i] = make_float4(m.albedo[0], m.albedo[1], m.albedo[2], m.emission);
     m1[i] = m.surface;
   }
-  std::vector<float4> sp0(s->num_spheres), sp1(s->num_spheres);
-  std::vector<int> sp2(s->num_spheres);
+  // Analytic objects: one material list in the order spheres, boxes, planes.
+  const size_t nobj = s->num_spheres + s->num_boxes + s->num_planes;
+  std::vector<float4> sp0(s->num_spheres), sp1(nobj), bx0(s->num_boxes), bx1(s->num_boxes), pl0(s->num_planes),
+      pl1(s->num_planes);
+  std::vector<int> sp2(nobj);
+  auto put_material = [&](size_t i, const rtx_material& m) {
+    sp1[i] = make_float4(m.albedo[0], m.albedo[1], m.albedo[2], m.emission);
+    sp2[i] = m.surface;
+  };
   for (size_t i = 0; i < s->num_spheres; i++) {
     const rtx_sphere& q = s->spheres[i];
     sp0[i] = make_float4(q.c[0], q.c[1], q.c[2], q.r);
-    sp1[i] = make_float4(q.material.albedo[0], q.material.albedo[1], q.material.albedo[2],
-                         q.material.emission);
-    sp2[i] = q.material.surface;
+    put_material(i, q.material);
+  }
+  for (size_t i = 0; i < s->num_boxes; i++) {
+    const rtx_box& q = s->boxes[i];
+    bx0[i] = make_float4(q.min[0], q.min[1], q.min[2], 0.f);
+    bx1[i] = make_float4(q.max[0], q.max[1], q.max[2], 0.f);
+    put_material(s->num_spheres + i, q.material);
+  }
+  for (size_t i = 0; i < s->num_planes; i++) {
+    const rtx_plane& q = s->planes[i];
+    pl0[i] = make_float4(q.point[0], q.point[1], q.point[2], 0.f);
+    pl1[i] = make_float4(q.normal[0], q.normal[1], q.normal[2], 0.f);
+    put_material(s->num_spheres + s->num_boxes + i, q.material);
   }
   // Light list, Scene::commit (Scene.h:129-141): triangles in order whose material
   // emission exceeds the threshold; per light the Triangle ctor's n and rcp_area
@@ -351,6 +371,10 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
   HIP_TRY(c->sph0.upload(sp0));
   HIP_TRY(c->sph1.upload(sp1));
   HIP_TRY(c->sph2.upload(sp2));
+  HIP_TRY(c->box0.upload(bx0));
+  HIP_TRY(c->box1.upload(bx1));
+  HIP_TRY(c->pln0.upload(pl0));
+  HIP_TRY(c->pln1.upload(pl1));
   HIP_TRY(c->light0.upload(l0));
   HIP_TRY(c->light1.upload(l1));
   HIP_TRY(c->light2.upload(l2));
@@ -360,6 +384,9 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
   d.nodes = c->nodes.p; d.tri0 = c->tri0.p; d.tri1 = c->tri1.p; d.tri2 = c->tri2.p;
   d.mat0 = c->mat0.p; d.mat1 = c->mat1.p;
   d.sph0 = c->sph0.p; d.sph1 = c->sph1.p; d.sph2 = c->sph2.p;
+  d.box0 = c->box0.p; d.box1 = c->box1.p; d.pln0 = c->pln0.p; d.pln1 = c->pln1.p;
+  d.num_boxes = (uint32_t)s->num_boxes;
+  d.num_planes = (uint32_t)s->num_planes;
   d.light0 = c->light0.p; d.light1 = c->light1.p; d.light2 = c->light2.p; d.light3 = c->light3.p;
   d.num_nodes = (uint32_t)nodes.size() / 4;
   d.num_tris = (uint32_t)nt;

@@ -5,6 +5,7 @@
 //   Material / Surface (Material.h:4-15)        rt::Material / rt::Surface (same layout)
 //   Triangle / Mesh (Obj.h:96-200)              rt::Triangle / rt::Mesh (add_triangle, add_material)
 //   Sphere (Obj.h:249-256)                      rt::Sphere
+//   Box (commented, Obj.h:35-93), Plane         rt::Box, rt::Plane
 //   Scene::load_mesh / addMesh / commit         rt::Scene::load_mesh / addMesh / commit
 //     (Scene.h:55-142)
 //   Img (Raytracer.cpp:47-144)                  rt::Img (pixels, sample_count, clear/get/set, save*)
@@ -55,6 +56,20 @@ struct Sphere {  // Obj.h:249-256
   Sphere(Vec3 c_, float r_) : c(c_), r(r_) {}
 };
 static_assert(sizeof(Sphere) == sizeof(rtx_sphere), "Sphere must match rtx_sphere");
+
+struct Box {  // the reference's commented-out class Box (Obj.h:35-93) + its material
+  Vec3 min, max;
+  Material material;
+  Box(Vec3 mn, Vec3 mx) : min(mn), max(mx) {}
+};
+static_assert(sizeof(Box) == sizeof(rtx_box), "Box must match rtx_box");
+
+struct Plane {  // Plane(point, normal) of the reference's scenes (Raytracer.cpp:184-221)
+  Vec3 point, normal;
+  Material material;
+  Plane(Vec3 p, Vec3 n) : point(p), normal(n) {}
+};
+static_assert(sizeof(Plane) == sizeof(rtx_plane), "Plane must match rtx_plane");
 
 struct Mesh {  // Obj.h:163-182
   std::vector<Triangle> triangles;
@@ -196,6 +211,8 @@ class Scene {
  public:
   std::vector<Mesh*> meshes;
   std::vector<Sphere> spheres;
+  std::vector<Box> boxes;
+  std::vector<Plane> planes;
 
   explicit Scene(const rtx_config& cfg) : cfg_(cfg) { check(rtx_create(&cfg_, &ctx_), "rtx_create"); }
   ~Scene() {
@@ -236,6 +253,10 @@ class Scene {
     s.num_materials = mats.size();
     s.spheres = reinterpret_cast<const rtx_sphere*>(spheres.data());
     s.num_spheres = spheres.size();
+    s.boxes = reinterpret_cast<const rtx_box*>(boxes.data());
+    s.num_boxes = boxes.size();
+    s.planes = reinterpret_cast<const rtx_plane*>(planes.data());
+    s.num_planes = planes.size();
     check(rtx_set_scene(ctx_, &s), "rtx_set_scene");
   }
 

@@ -23,7 +23,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .capi import MATERIAL_DTYPE, SPHERE_DTYPE, SceneData
+from .capi import BOX_DTYPE, MATERIAL_DTYPE, PLANE_DTYPE, SPHERE_DTYPE, SceneData
 
 DIFFUSE, SPECULAR, REFLECTIVE, VARNISH = 0, 1, 2, 3
 
@@ -42,6 +42,22 @@ def sphere(c, r, mat):
     s["r"] = r
     s["material"] = mat
     return s
+
+
+def box_obj(mn, mx, mat):
+    b = np.zeros((), BOX_DTYPE)
+    b["min"] = mn
+    b["max"] = mx
+    b["material"] = mat
+    return b
+
+
+def plane_obj(point, normal, mat):
+    p = np.zeros((), PLANE_DTYPE)
+    p["point"] = point
+    p["normal"] = normal
+    p["material"] = mat
+    return p
 
 
 def quad(p0, p1, p2, p3):
@@ -151,6 +167,51 @@ def oven(emission=0.5, albedo=0.5) -> SceneData:
     tris = np.concatenate([q for _, q in room(-2, 2, -1, 3, -2, 4, front=True)])
     mats = np.array([material((albedo,) * 3, emission)], MATERIAL_DTYPE)
     return SceneData(tris, np.zeros(len(tris), np.uint32), mats, name="oven")
+
+
+def reference_scene(i: int) -> SceneData:
+    """The reference's commented-out analytic scenes (Raytracer.cpp:180-226): planes, spheres and
+    axis-aligned boxes only, no mesh (so no NEE: the light list holds mesh triangles only).
+    0: a plane, a glass sphere and a glass box (lit by the sky: use sky=1)
+    1: Cornell box of six planes at +-800 with a glass sphere, a glass box and a box light
+    2: the oven test: six planes of emission 0.5 / albedo 0.5
+    3: Cornell planes with a diffuse sphere and a box light
+    The +-800 rooms are centred on the origin like the reference's; the camera of Camera.h:23 at
+    (0,1,3) is inside them."""
+    mirror = material((1, 1, 1), 0.0, REFLECTIVE)  # noqa: F841  (mirrorMat, unused by the scenes as in the reference)
+    dif = material(WHITE)
+    red, green = material(RED), material(GREEN)
+    glass = material((1, 1, 1), 0.0, SPECULAR)
+    light = material((1, 1, 1), 16.0, SPECULAR)   # lightMat, Raytracer.cpp:159
+    oven_m = material((0.5, 0.5, 0.5), 0.5)
+    no_mesh = dict(triangles=np.zeros((0, 9), np.float32), material_index=np.zeros(0, np.uint32),
+                   materials=np.array([dif], MATERIAL_DTYPE))
+
+    def walls(m_back, m_front, m_top, m_bottom, m_right, m_left):
+        return [plane_obj((0, 0, -800), (0, 0, 1), m_back), plane_obj((0, 0, 800), (0, 0, -1), m_front),
+                plane_obj((0, 800, 0), (0, -1, 0), m_top), plane_obj((0, -800, 0), (0, 1, 0), m_bottom),
+                plane_obj((800, 0, 0), (-1, 0, 0), m_right), plane_obj((-800, 0, 0), (1, 0, 0), m_left)]
+
+    if i == 0:
+        return SceneData(**no_mesh, name="ref_scene0",
+                         planes=np.array([plane_obj((0, 2.05, 0), (0, -1, 0), dif)], PLANE_DTYPE),
+                         spheres=np.array([sphere((1.7, 0.5, -4.0), 1.3, glass)], SPHERE_DTYPE),
+                         boxes=np.array([box_obj((-1.4, 0.5, -3.0), (-0.4, 1.5, -2.0), glass)], BOX_DTYPE))
+    if i == 1:
+        return SceneData(**no_mesh, name="ref_scene1",
+                         planes=np.array(walls(dif, dif, dif, dif, green, red), PLANE_DTYPE),
+                         spheres=np.array([sphere((400, 440, -600), 200.3, glass)], SPHERE_DTYPE),
+                         boxes=np.array([box_obj((-200, -800, -500), (200, -750, -100), glass),
+                                         box_obj((-200, -800, -500), (200, -799.9, -100), light)], BOX_DTYPE))
+    if i == 2:
+        return SceneData(**no_mesh, name="ref_scene2_oven",
+                         planes=np.array(walls(*([oven_m] * 6)), PLANE_DTYPE))
+    if i == 3:
+        return SceneData(**no_mesh, name="ref_scene3",
+                         planes=np.array(walls(dif, dif, dif, dif, green, red), PLANE_DTYPE),
+                         spheres=np.array([sphere((0, -40, -500), 200.3, dif)], SPHERE_DTYPE),
+                         boxes=np.array([box_obj((-50, -800, -650), (50, -799.9, -550), light)], BOX_DTYPE))
+    raise ValueError("scene index 0..3")
 
 
 def _hash32(x: np.ndarray) -> np.ndarray:

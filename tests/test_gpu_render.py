@@ -55,12 +55,15 @@ def test_normals_integrator_bit_exact(oracle, rtx_lib):
 @pytest.mark.parametrize("name,sky,camera", [
     ("cornell", 0, 0), ("cornell_4l", 0, 0), ("sample1", 1, 0), ("sample2", 1, 0),
     ("cornell_thinlens", 0, 1), ("cornell_ortho", 0, 2), ("soup", 1, 0),
+    ("ref_scene0", 1, 0), ("ref_scene1", 0, 0), ("ref_scene3", 0, 0),
 ])
 def test_one_spp_per_path_parity(name, sky, camera, finish_paths, oracle, rtx_lib):
     sc = {"cornell": scenes.cornell, "cornell_4l": lambda: scenes.cornell(lights=4),
           "sample1": scenes.sphere_sky, "sample2": lambda: scenes.sphere_sky(glass=True),
           "cornell_thinlens": scenes.cornell, "cornell_ortho": scenes.cornell,
-          "soup": lambda: scenes.soup(3000, 3)}[name]()
+          "soup": lambda: scenes.soup(3000, 3),
+          "ref_scene0": lambda: scenes.reference_scene(0), "ref_scene1": lambda: scenes.reference_scene(1),
+          "ref_scene3": lambda: scenes.reference_scene(3)}[name]()
     cfg = Config(width=128, height=128, sky=sky, camera=camera, fov=60.0 if camera == 1 else 50.0,
                  pool_paths=1 << 12,  # pool < pixels: the queue is refilled several times
                  finish_paths=finish_paths)
@@ -69,7 +72,10 @@ def test_one_spp_per_path_parity(name, sky, camera, finish_paths, oracle, rtx_li
     assert st.paths == ost.paths == 128 * 128
     frac = close_fraction(got, want)
     assert frac >= 0.99, f"{name}: only {frac:.4f} of pixels agree"
-    assert abs(st.bounces - ost.bounces) <= 0.005 * ost.bounces, (st.bounces, ost.bounces)
+    # Closed +-800 rooms with glass: a path that diverges by one decision can differ by hundreds
+    # of bounces, so the totals of 16k paths get a wider band there.
+    btol = 0.02 if name in ("ref_scene1", "ref_scene3") else 0.005
+    assert abs(st.bounces - ost.bounces) <= btol * ost.bounces, (st.bounces, ost.bounces)
     assert abs(st.nee_samples - ost.nee_samples) <= 0.005 * max(ost.nee_samples, 1)
     assert np.isfinite(got).all() == np.isfinite(want).all()
 
@@ -94,14 +100,16 @@ def test_converged_image_parity(oracle, rtx_lib):
     assert cross <= 1.25 * noise, (cross, noise)
 
 
-def test_oven_box_is_one(rtx_lib):
+@pytest.mark.parametrize("make", [scenes.oven, lambda: scenes.reference_scene(2)], ids=["triangles", "planes"])
+def test_oven_box_is_one(make, rtx_lib):
+    """The reference's oven test (Raytracer.cpp:203-214), from triangles and from its six planes."""
     cfg = Config(width=64, height=64)
     spp = 256
-    got, st, _ = gpu_render(cfg, scenes.oven(), spp)
+    got, st, _ = gpu_render(cfg, make(), spp)
     img = got / spp
     assert abs(img.mean() - 1.0) < 0.005, img.mean()
     assert np.isfinite(img).all()
-    assert st.nee_samples == 0  # emission 0.5 >= threshold: NEE is skipped (Integrator.h:209)
+    assert st.nee_samples == 0  # emission 0.5 >= threshold, or no mesh lights: NEE is skipped (Integrator.h:209)
 
 
 def test_sample_ranges_row_bands_and_chunks_are_bit_identical(rtx_lib):

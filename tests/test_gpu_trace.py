@@ -42,6 +42,9 @@ SCENES = {
     "one_triangle": lambda: scenes.SceneData(scenes.quad((-1, 0, 0), (1, 0, 0), (1, 2, 0), (-1, 2, 0))[:1],
                                              np.zeros(1, np.uint32),
                                              np.array([scenes.material(scenes.WHITE)], scenes.MATERIAL_DTYPE)),
+    "ref_scene0": lambda: scenes.reference_scene(0),
+    "ref_scene1": lambda: scenes.reference_scene(1),
+    "ref_scene3": lambda: scenes.reference_scene(3),
     "spheres_only": lambda: scenes.SceneData(np.zeros((0, 9), np.float32), np.zeros(0, np.uint32),
                                              np.array([scenes.material(scenes.WHITE)], scenes.MATERIAL_DTYPE),
                                              scenes.soup(1, 4).spheres),
@@ -69,6 +72,8 @@ def test_closest_hit_bit_exact(name, oracle, rtx_lib):
         prim = camera_rays(oracle, cfg)
         sets = [prim, bounce_rays(oracle, osc, prim), scenes.random_rays(20000, seed=11),
                 scenes.random_rays(5000, seed=12, unit=False)]
+        if name.startswith("ref_scene"):   # rays inside the +-800 rooms too
+            sets.append(scenes.random_rays(20000, seed=13, origin_box=((-790, -790, -790), (790, 790, 790))))
         for rays in sets:
             if rays.shape[0] == 0:
                 continue
@@ -77,7 +82,7 @@ def test_closest_hit_bit_exact(name, oracle, rtx_lib):
             assert_same_hits(got, want)
 
 
-@pytest.mark.parametrize("name", ["cornell", "soup10k", "sphere_sky", "spheres_only"])
+@pytest.mark.parametrize("name", ["cornell", "soup10k", "sphere_sky", "spheres_only", "ref_scene0", "ref_scene1"])
 def test_occlusion_bit_exact(name, oracle, rtx_lib):
     cfg = Config(width=800, height=800, pool_paths=1 << 16)
     sc = SCENES[name]()
@@ -86,13 +91,15 @@ def test_occlusion_bit_exact(name, oracle, rtx_lib):
     rays = np.concatenate([scenes.random_rays(20000, seed=21),
                            bounce_rays(oracle, osc, camera_rays(oracle, cfg, 64))])
     dist = rng.uniform(0.0, 3.0, rays.shape[0]).astype(np.float32)
+    if name == "ref_scene1":
+        dist *= 400
     dist[:50] = rng.uniform(0.0, 0.003, 50)  # exercises distance < 2*eps (Scene.h:192-194)
     with Renderer(cfg) as r:
         r.set_scene(sc)
         got = r.trace_occluded(rays, dist)
     want = osc.trace_occluded(rays, dist, use_bvh=False)
     assert np.array_equal(got, want), f"{np.count_nonzero(got != want)} of {got.size} segments differ"
-    assert 0 < want.sum() < want.size or name == "spheres_only"
+    assert 0 < want.sum() < want.size or name in ("spheres_only", "ref_scene0")
 
 
 def test_empty_inputs(rtx_lib):

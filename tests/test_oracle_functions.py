@@ -153,3 +153,22 @@ def test_img_update_running_mean_vs_sum(oracle):
     for s in samples:
         total += s
     np.testing.assert_allclose(px, total / np.float32(len(samples)), rtol=2e-5)
+
+
+def test_box_and_plane(oracle):
+    """Box follows the reference's commented-out class (Obj.h:43-87); Plane is build-defined."""
+    mn, mx = (-1, -1, -1), (1, 1, 1)
+    assert oracle.box_intersect(mn, mx, (0, 0, 3), (0, 0, -1)) == 2.0
+    assert oracle.box_intersect(mn, mx, (0, 0, 0), (0, 0, -1)) == 1.0       # inside: tmin <= EPS -> tmax
+    assert oracle.box_intersect(mn, mx, (0, 3, 3), (0, 0, -1)) == math.inf  # misses the y slab
+    assert oracle.box_intersect(mn, mx, (0, 0, 3), (0, 0, 1)) < 0           # behind: negative, caller rejects
+    # axis-parallel ray inside the other slabs: divisions by zero give +-inf, folded by min/max
+    assert oracle.box_intersect(mn, mx, (0.5, 0.5, 3), (0, 0, -1)) == 2.0
+    np.testing.assert_array_equal(oracle.box_normal(mn, mx, (0.2, 0.3, 1.0)), (0, 0, 1))
+    np.testing.assert_array_equal(oracle.box_normal(mn, mx, (-1.0, 0.3, 0.5)), (-1, 0, 0))
+    # a thin box: the face is chosen relative to the extent on each axis
+    np.testing.assert_array_equal(oracle.box_normal((-2, -0.1, -2), (2, 0.1, 2), (1.5, 0.1, 0.0)), (0, 1, 0))
+    assert oracle.plane_intersect((0, 0, 0), (0, 1, 0), (0, 2, 0), (0, -1, 0)) == 2.0
+    assert oracle.plane_intersect((0, 0, 0), (0, 1, 0), (0, 2, 0), (0, 1, 0)) == -2.0
+    t = oracle.plane_intersect((0, 0, 0), (0, 1, 0), (0, 2, 0), (1, 0, 0))   # parallel: -inf (or NaN), never a hit
+    assert not (1e-3 < t < math.inf)

@@ -104,3 +104,20 @@ def test_max_bounces_and_integrators(oracle):
     assert st.bounces <= 2 * st.paths
     nrm, st = oracle.OracleScene(sc, Config(width=32, height=32, integrator=1)).render(1)
     assert st.bounces == st.paths and nrm.min() >= 0 and nrm.max() <= 1.8
+
+
+def test_analytic_scenes_of_the_reference(oracle):
+    """The commented-out scenes of Raytracer.cpp:180-226 built from planes, spheres and boxes.
+    Scene 2 is the reference's own oven test: six planes of emission 0.5 / albedo 0.5 -> 1."""
+    cfg = Config(width=32, height=32)
+    img, st = oracle.OracleScene(scenes.reference_scene(2), cfg).render(192)
+    assert abs((img / 192).mean() - 1.0) < 0.01 and st.nee_samples == 0
+    osc = oracle.OracleScene(scenes.reference_scene(1), cfg)
+    assert osc.num_lights == 0          # no mesh -> nothing for NEE to sample (Scene.h:129-141)
+    kind, prim, t, n = osc.trace_closest(np.array([[0, 1, 3, 0, 0, -1], [0, 1, -300, 0, -1, 0], [0, 1, 3, 1, 0, 0]], np.float32))
+    assert list(kind) == [4, 3, 4] and list(prim) == [0, 0, 4]   # back plane, the glass box's top, right plane
+    np.testing.assert_array_equal(n, [(0, 0, 1), (0, 1, 0), (-1, 0, 0)])
+    assert t[0] == 803.0 and t[1] == 751.0 and t[2] == 800.0
+    # occlusion by analytic objects
+    occ = osc.trace_occluded(np.array([[0, 1, -300, 0, -1, 0]] * 2, np.float32), np.array([700.0, 900.0], np.float32))
+    assert list(occ) == [0, 1]
