@@ -144,6 +144,8 @@ typedef struct {
 typedef struct {
   uint32_t num_nodes, num_triangles, num_lights, num_spheres, max_depth, stack_entries;
   double build_ms;
+  uint32_t bvh_width;    /* children per BVH node: 2 (scenes staged in LDS) or 4 (quantised, large scenes) */
+  uint32_t stack_bound;  /* worst-case traversal stack entries (those beyond stack_entries spill to memory) */
 } rtx_scene_info;
 
 typedef struct rtx_ctx rtx_ctx;

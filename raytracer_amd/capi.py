@@ -85,7 +85,7 @@ class SceneInfo(C.Structure):
     _fields_ = [
         ("num_nodes", C.c_uint32), ("num_triangles", C.c_uint32), ("num_lights", C.c_uint32),
         ("num_spheres", C.c_uint32), ("max_depth", C.c_uint32), ("stack_entries", C.c_uint32),
-        ("build_ms", C.c_double),
+        ("build_ms", C.c_double), ("bvh_width", C.c_uint32), ("stack_bound", C.c_uint32),
     ]
 
 

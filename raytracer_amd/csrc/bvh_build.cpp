@@ -203,13 +203,119 @@ struct Flattener {
   }
 };
 
+// Width-4 flattening with 8-bit child boxes (format: bvh_build.h).
+struct Flattener4 {
+  const std::vector<TmpNode>& tmp;
+  std::vector<float>& out;
+  uint32_t max_depth = 0;
+
+  static int32_t leaf_ref(const TmpNode& n) { return ~(int32_t)((n.first << 3) | (n.count - 1)); }
+
+  int32_t emit(int32_t t, uint32_t depth) {
+    const int32_t idx = (int32_t)(out.size() / 16);
+    out.resize(out.size() + 16, 0.f);
+    max_depth = std::max(max_depth, depth + 1);
+    // Pull grandchildren up, largest box first, until there are four children.
+    int32_t kids[4] = {tmp[t].left, tmp[t].right, -1, -1};
+    int nk = 2;
+    while (nk < 4) {
+      int best = -1;
+      float best_area = -1.f;
+      for (int k = 0; k < nk; k++)
+        if (tmp[kids[k]].left >= 0 && tmp[kids[k]].box.half_area() > best_area) {
+          best_area = tmp[kids[k]].box.half_area();
+          best = k;
+        }
+      if (best < 0) break;
+      const int32_t inner = kids[best];
+      kids[best] = tmp[inner].left;
+      kids[nk++] = tmp[inner].right;
+    }
+    float lo[4][3], hi[4][3], plo[3], phi[3];
+    for (int k = 0; k < 3; k++) {
+      plo[k] = std::numeric_limits<float>::infinity();
+      phi[k] = -std::numeric_limits<float>::infinity();
+    }
+    for (int c = 0; c < nk; c++) {
+      Flattener::padded(tmp[kids[c]].box, lo[c], hi[c]);
+      for (int k = 0; k < 3; k++) {
+        plo[k] = std::min(plo[k], lo[c][k]);
+        phi[k] = std::max(phi[k], hi[c][k]);
+      }
+    }
+    uint32_t ebyte[3];
+    float scale[3];
+    for (int k = 0; k < 3; k++) {
+      // smallest power of two with 255 * scale >= extent (in float arithmetic)
+      int e = 0;
+      float ext = phi[k] - plo[k];
+      std::frexp(ext / 255.0f, &e);  // ext/255 = m * 2^e, m in [0.5, 1)  ->  2^e > ext/255
+      int biased = std::min(std::max(e + 127, 1), 254);
+      uint32_t bits = (uint32_t)biased << 23;
+      std::memcpy(&scale[k], &bits, 4);
+      while (plo[k] + 255.0f * scale[k] < phi[k] && biased < 254) {  // rounding safety
+        biased++;
+        bits = (uint32_t)biased << 23;
+        std::memcpy(&scale[k], &bits, 4);
+      }
+      ebyte[k] = (uint32_t)biased;
+    }
+    uint32_t qlo[3] = {0, 0, 0}, qhi[3] = {0, 0, 0};
+    for (int c = 0; c < 4; c++) {
+      for (int k = 0; k < 3; k++) {
+        uint32_t a = 255, b = 0;  // absent child: inverted box
+        if (c < nk) {
+          int ia = (int)std::floor((lo[c][k] - plo[k]) / scale[k]);
+          int ib = (int)std::ceil((hi[c][k] - plo[k]) / scale[k]);
+          ia = std::min(std::max(ia, 0), 255);
+          ib = std::min(std::max(ib, 0), 255);
+          // The decoded planes must enclose the child box in float arithmetic too.
+          while (ia > 0 && plo[k] + (float)ia * scale[k] > lo[c][k]) ia--;
+          while (ib < 255 && plo[k] + (float)ib * scale[k] < hi[c][k]) ib++;
+          a = (uint32_t)ia;
+          b = (uint32_t)ib;
+        }
+        qlo[k] |= a << (8 * c);
+        qhi[k] |= b << (8 * c);
+      }
+    }
+    int32_t refs[4];
+    for (int c = 0; c < 4; c++) {
+      if (c >= nk)
+        refs[c] = (int32_t)0x80000000u;
+      else if (tmp[kids[c]].left < 0)
+        refs[c] = leaf_ref(tmp[kids[c]]);
+      else
+        refs[c] = emit(kids[c], depth + 1);
+    }
+    float* q = &out[(size_t)idx * 16];
+    auto put_u = [&](int i, uint32_t v) { std::memcpy(&q[i], &v, 4); };
+    q[0] = plo[0];
+    q[1] = plo[1];
+    q[2] = plo[2];
+    put_u(3, ebyte[0] | (ebyte[1] << 8) | (ebyte[2] << 16));
+    put_u(4, qlo[0]);
+    put_u(5, qlo[1]);
+    put_u(6, qlo[2]);
+    put_u(7, qhi[0]);
+    put_u(8, qhi[1]);
+    put_u(9, qhi[2]);
+    put_u(10, 0);
+    put_u(11, 0);
+    for (int c = 0; c < 4; c++) put_u(12 + c, (uint32_t)refs[c]);
+    return idx;
+  }
+};
+
 }  // namespace
 
-void build_bvh(const float* tris, size_t ntri, uint32_t max_leaf, FlatBvh& out) {
+void build_bvh(const float* tris, size_t ntri, uint32_t max_leaf, uint32_t width, FlatBvh& out) {
   const uint32_t kMaxLeaf = max_leaf < 1 ? 1u : (max_leaf > 8 ? 8u : max_leaf);
   out.nodes.clear();
   out.order.clear();
   out.max_depth = 0;
+  out.max_stack = 0;
+  out.width = width == 4 ? 4 : 2;
   if (ntri == 0) return;  // no mesh: the kernels skip the traversal when there are no nodes
   std::vector<Box> tb(ntri);
   std::vector<float> cent(3 * ntri);
@@ -231,6 +337,15 @@ void build_bvh(const float* tris, size_t ntri, uint32_t max_leaf, FlatBvh& out) 
   for (const TmpNode& n : b.nodes)
     if (n.left < 0) std::sort(out.order.begin() + n.first, out.order.begin() + n.first + n.count);
 
+  if (out.width == 4 && b.nodes[root].left >= 0) {
+    Flattener4 f4{b.nodes, out.nodes};
+    out.nodes.reserve(16 * ntri / 4 + 16);
+    f4.emit(root, 0);
+    out.max_depth = f4.max_depth;
+    out.max_stack = 3 * f4.max_depth;
+    return;
+  }
+  out.width = 2;  // (a mesh that fits one leaf keeps the two-child root below)
   Flattener f{b.nodes, out.nodes};
   out.nodes.reserve(16 * ntri / 2 + 16);
   if (b.nodes[root].left < 0) {
@@ -255,10 +370,12 @@ void build_bvh(const float* tris, size_t ntri, uint32_t max_leaf, FlatBvh& out) 
     q[12] = as_float(~(int32_t)((0u << 3) | (h - 1)));
     q[13] = as_float(~(int32_t)((first1 << 3) | (cnt1 - 1)));
     out.max_depth = 1;
+    out.max_stack = 1;
     return;
   }
   f.emit_inner(root, 0);
   out.max_depth = f.max_depth;
+  out.max_stack = f.max_depth;
 }
 
 }  // namespace rtx

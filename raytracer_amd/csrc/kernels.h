@@ -141,6 +141,35 @@ struct Geom {
   const float4* tri1;
   const float4* tri2;
 };
+
+// How a traversal kernel reads the tree.
+enum TraceMode {
+  kGlobalBvh2 = 0,  // two-child nodes in global memory
+  kLdsBvh2 = 1,     // two-child nodes and triangles staged in LDS (small scenes)
+  kGlobalBvh4 = 2,  // four-child quantised nodes in global memory (large scenes)
+};
+
+// Per-lane traversal stack: the first lds_entries entries live in LDS (one column
+// per lane, `stride` ints apart); deeper entries, which a well-built tree needs
+// only for rare rays, go to a global array with one column per launched thread.
+struct Stack {
+  int* lds;
+  int* spill;
+  int stride;          // LDS column stride (threads per block)
+  int lds_entries;
+  uint32_t spill_stride;  // threads per launch
+  __device__ __forceinline__ void push(int& sp, int v) const {
+    if (sp < lds_entries)
+      lds[sp * stride] = v;
+    else
+      spill[(size_t)(sp - lds_entries) * spill_stride] = v;
+    sp++;
+  }
+  __device__ __forceinline__ int pop(int& sp) const {
+    sp--;
+    return sp < lds_entries ? lds[sp * stride] : spill[(size_t)(sp - lds_entries) * spill_stride];
+  }
+};
 __device__ __forceinline__ Geom global_geom(const SceneDev& sc) {
   Geom g;
   g.nodes = sc.nodes;
@@ -249,118 +278,226 @@ __device__ __forceinline__ bool slab(float lox, float hix, float loy, float hiy,
   return tn <= tf * 1.0000004f;
 }
 
-// Closest mesh hit with the rules of Mesh::intersect (reference Obj.h:184-195):
-// a hit needs eps < t; the smallest t wins and, among equal t, the lowest
-// primitive id (the linear scan keeps the first).  `stk` is this lane's column
-// of the block's LDS stack; consecutive entries are `stride` ints apart.
-__device__ __forceinline__ void mesh_closest(const SceneDev& sc, const Geom& g, f3 o, f3 d, int* stk,
-                                             int stride, float& best_t, uint32_t& best_slot) {
+// One triangle of a leaf against the running closest hit, with the rules of
+// Mesh::intersect (reference Obj.h:184-195): a hit needs eps < t; the smallest t
+// wins and, among equal t, the lowest primitive id (the linear scan keeps the first).
+__device__ __forceinline__ void leaf_closest(const Geom& g, uint32_t leaf, f3 o, f3 d, float eps,
+                                             float& best_t, uint32_t& best_prim, uint32_t& best_slot) {
+  uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
+  for (uint32_t k = 0; k < cnt; k++) {
+    uint32_t slot = first + k;
+    float4 A = g.tri0[slot], B = g.tri1[slot], C = g.tri2[slot];
+    float t = tri_intersect(mk3(A.x, A.y, A.z), mk3(B.x, B.y, B.z), mk3(C.x, C.y, C.z), o, d);
+    uint32_t prim = __float_as_uint(A.w);
+    if (eps < t && t < INFINITY && (t < best_t || (t == best_t && prim < best_prim))) {
+      best_t = t;
+      best_prim = prim;
+      best_slot = slot;
+    }
+  }
+}
+// Any triangle of a leaf with eps < t < tfar (the interval Scene::isOccluded gives
+// Embree, reference Scene.h:216-217, ends taken open as in Mesh::intersect).
+__device__ __forceinline__ bool leaf_any(const Geom& g, uint32_t leaf, f3 o, f3 d, float eps, float tfar) {
+  uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
+  bool hit = false;
+  for (uint32_t k = 0; k < cnt; k++) {
+    uint32_t slot = first + k;
+    float4 A = g.tri0[slot], B = g.tri1[slot], C = g.tri2[slot];
+    float t = tri_intersect(mk3(A.x, A.y, A.z), mk3(B.x, B.y, B.z), mk3(C.x, C.y, C.z), o, d);
+    if (eps < t && t < tfar) hit = true;
+  }
+  return hit;
+}
+
+// The four children of a quantised node against [0, tmax].  a_k = scale_k/d_k and
+// b_k = (origin_k - o_k)/d_k turn a plane byte q into t = q*a_k + b_k (one fma; the
+// boxes are padded and quantised outwards by far more than its rounding).  The near
+// and far plane of each axis are picked by the direction's sign, so an inverted box
+// (an absent child: lo = 255, hi = 0) always misses.  |d_k| is clamped away from zero
+// for this test only, which keeps every term finite.
+struct Node4Test {
+  float tn[4];
+  bool hit[4];
+};
+__device__ __forceinline__ float ubyte_f(uint32_t w, int i) { return (float)((w >> (8 * i)) & 0xffu); }
+__device__ __forceinline__ Node4Test test_node4(const float4* nd, f3 o, f3 inv, float tmax, int4& refs) {
+  float4 q0 = nd[0], q1f = nd[1], q2f = nd[2], q3f = nd[3];
+  const uint32_t ew = __float_as_uint(q0.w);
+  const float ax = __uint_as_float((ew & 0xffu) << 23) * inv.x;
+  const float ay = __uint_as_float(((ew >> 8) & 0xffu) << 23) * inv.y;
+  const float az = __uint_as_float(((ew >> 16) & 0xffu) << 23) * inv.z;
+  const float bx = (q0.x - o.x) * inv.x, by = (q0.y - o.y) * inv.y, bz = (q0.z - o.z) * inv.z;
+  const uint32_t lox = __float_as_uint(q1f.x), loy = __float_as_uint(q1f.y), loz = __float_as_uint(q1f.z);
+  const uint32_t hix = __float_as_uint(q1f.w), hiy = __float_as_uint(q2f.x), hiz = __float_as_uint(q2f.y);
+  const uint32_t nx = inv.x < 0.0f ? hix : lox, fx = inv.x < 0.0f ? lox : hix;
+  const uint32_t ny = inv.y < 0.0f ? hiy : loy, fy = inv.y < 0.0f ? loy : hiy;
+  const uint32_t nz = inv.z < 0.0f ? hiz : loz, fz = inv.z < 0.0f ? loz : hiz;
+  refs = make_int4(__float_as_int(q3f.x), __float_as_int(q3f.y), __float_as_int(q3f.z), __float_as_int(q3f.w));
+  const int r[4] = {refs.x, refs.y, refs.z, refs.w};
+  Node4Test out;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    float tnx = __builtin_fmaf(ubyte_f(nx, i), ax, bx), tfx = __builtin_fmaf(ubyte_f(fx, i), ax, bx);
+    float tny = __builtin_fmaf(ubyte_f(ny, i), ay, by), tfy = __builtin_fmaf(ubyte_f(fy, i), ay, by);
+    float tnz = __builtin_fmaf(ubyte_f(nz, i), az, bz), tfz = __builtin_fmaf(ubyte_f(fz, i), az, bz);
+    float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+    float tf = fminf(fminf(tfx, tfy), fminf(tfz, tmax));
+    out.tn[i] = tn;
+    out.hit[i] = tn <= tf * 1.0000004f && r[i] != kTraversalDone;
+  }
+  return out;
+}
+__device__ __forceinline__ f3 safe_inverse(f3 d) {
+  const float tiny = 1.0e-20f;
+  float x = fabsf(d.x) < tiny ? copysignf(tiny, d.x) : d.x;
+  float y = fabsf(d.y) < tiny ? copysignf(tiny, d.y) : d.y;
+  float z = fabsf(d.z) < tiny ? copysignf(tiny, d.z) : d.z;
+  return mk3(1.0f / x, 1.0f / y, 1.0f / z);
+}
+__device__ __forceinline__ void order2(float& ta, int& ra, float& tb, int& rb) {
+  if (tb < ta) {
+    float t = ta;
+    ta = tb;
+    tb = t;
+    int r = ra;
+    ra = rb;
+    rb = r;
+  }
+}
+
+// Closest mesh hit.  "while-while" traversal: all lanes of the wave first walk inner
+// nodes until each holds a leaf (or is done), then all test triangles; the two phases
+// do not mix within an iteration, which keeps more lanes busy in each.
+template <int MODE>
+__device__ __forceinline__ void mesh_closest(const SceneDev& sc, const Geom& g, f3 o, f3 d, const Stack& stk,
+                                             float& best_t, uint32_t& best_slot) {
   best_t = INFINITY;
   best_slot = kMiss;
   if (sc.num_nodes == 0) return;
   uint32_t best_prim = kMiss;
   const float eps = sc.eps;
-  f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   int cur = 0;
   int sp = 0;
-  // "while-while" traversal: all lanes of the wave first walk inner nodes until each
-  // holds a leaf (or is done), then all test triangles; the two phases do not mix
-  // within an iteration, which keeps more lanes busy in each.
-  while (cur != kTraversalDone) {
-    while (cur >= 0) {
-      const float4* nd = g.nodes + 4 * (size_t)cur;
-      float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-      float tn0, tn1;
-      bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, o, inv, best_t, tn0);
-      bool h1 = slab(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, o, inv, best_t, tn1);
-      int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-      if (h0 && h1) {
-        bool swap = tn1 < tn0;
-        stk[sp * stride] = swap ? c0 : c1;
-        sp++;
-        cur = swap ? c1 : c0;
-      } else if (h0) {
-        cur = c0;
-      } else if (h1) {
-        cur = c1;
-      } else if (sp == 0) {
-        cur = kTraversalDone;
-      } else {
-        sp--;
-        cur = stk[sp * stride];
-      }
-    }
-    while (cur < 0 && cur != kTraversalDone) {
-      uint32_t v = ~(uint32_t)cur;
-      uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
-      for (uint32_t k = 0; k < cnt; k++) {
-        uint32_t slot = first + k;
-        float4 A = g.tri0[slot], B = g.tri1[slot], C = g.tri2[slot];
-        float t = tri_intersect(mk3(A.x, A.y, A.z), mk3(B.x, B.y, B.z), mk3(C.x, C.y, C.z), o, d);
-        uint32_t prim = __float_as_uint(A.w);
-        if (eps < t && t < INFINITY && (t < best_t || (t == best_t && prim < best_prim))) {
-          best_t = t;
-          best_prim = prim;
-          best_slot = slot;
+  if (MODE == kGlobalBvh4) {
+    const f3 inv = safe_inverse(d);
+    while (cur != kTraversalDone) {
+      while (cur >= 0) {
+        int4 refs;
+        Node4Test nt = test_node4(g.nodes + 4 * (size_t)cur, o, inv, best_t, refs);
+        float t0 = nt.hit[0] ? nt.tn[0] : INFINITY, t1 = nt.hit[1] ? nt.tn[1] : INFINITY;
+        float t2 = nt.hit[2] ? nt.tn[2] : INFINITY, t3 = nt.hit[3] ? nt.tn[3] : INFINITY;
+        int r0 = refs.x, r1 = refs.y, r2 = refs.z, r3 = refs.w;
+        // sort the four by entry distance (misses at +inf sink to the end)
+        order2(t0, r0, t1, r1);
+        order2(t2, r2, t3, r3);
+        order2(t0, r0, t2, r2);
+        order2(t1, r1, t3, r3);
+        order2(t1, r1, t2, r2);
+        if (t0 < INFINITY) {
+          if (t3 < INFINITY) stk.push(sp, r3);
+          if (t2 < INFINITY) stk.push(sp, r2);
+          if (t1 < INFINITY) stk.push(sp, r1);
+          cur = r0;
+        } else {
+          cur = sp == 0 ? kTraversalDone : stk.pop(sp);
         }
       }
-      if (sp == 0) {
-        cur = kTraversalDone;
-      } else {
-        sp--;
-        cur = stk[sp * stride];
+      while (cur < 0 && cur != kTraversalDone) {
+        leaf_closest(g, ~(uint32_t)cur, o, d, eps, best_t, best_prim, best_slot);
+        cur = sp == 0 ? kTraversalDone : stk.pop(sp);
+      }
+    }
+  } else {
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    while (cur != kTraversalDone) {
+      while (cur >= 0) {
+        const float4* nd = g.nodes + 4 * (size_t)cur;
+        float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+        float tn0, tn1;
+        bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, o, inv, best_t, tn0);
+        bool h1 = slab(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, o, inv, best_t, tn1);
+        int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+        if (h0 && h1) {
+          bool swap = tn1 < tn0;
+          stk.push(sp, swap ? c0 : c1);
+          cur = swap ? c1 : c0;
+        } else if (h0) {
+          cur = c0;
+        } else if (h1) {
+          cur = c1;
+        } else {
+          cur = sp == 0 ? kTraversalDone : stk.pop(sp);
+        }
+      }
+      while (cur < 0 && cur != kTraversalDone) {
+        leaf_closest(g, ~(uint32_t)cur, o, d, eps, best_t, best_prim, best_slot);
+        cur = sp == 0 ? kTraversalDone : stk.pop(sp);
       }
     }
   }
 }
 
-// Any mesh hit with eps < t < tfar (the interval Scene::isOccluded gives Embree,
-// reference Scene.h:216-217, ends taken open as in Mesh::intersect).
+// Any mesh hit with eps < t < tfar.
+template <int MODE>
 __device__ __forceinline__ bool mesh_any(const SceneDev& sc, const Geom& g, f3 o, f3 d, float tfar,
-                                         int* stk, int stride) {
+                                         const Stack& stk) {
   if (sc.num_nodes == 0) return false;
   const float eps = sc.eps;
-  f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   int cur = 0;
   int sp = 0;
   bool hit = false;
-  while (cur != kTraversalDone) {
-    while (cur >= 0) {
-      const float4* nd = g.nodes + 4 * (size_t)cur;
-      float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-      float tn0, tn1;
-      bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, o, inv, tfar, tn0);
-      bool h1 = slab(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, o, inv, tfar, tn1);
-      int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-      if (h0 && h1) {
-        stk[sp * stride] = c1;
-        sp++;
-        cur = c0;
-      } else if (h0) {
-        cur = c0;
-      } else if (h1) {
-        cur = c1;
-      } else if (sp == 0) {
-        cur = kTraversalDone;
-      } else {
-        sp--;
-        cur = stk[sp * stride];
+  if (MODE == kGlobalBvh4) {
+    const f3 inv = safe_inverse(d);
+    while (cur != kTraversalDone) {
+      while (cur >= 0) {
+        int4 refs;
+        Node4Test nt = test_node4(g.nodes + 4 * (size_t)cur, o, inv, tfar, refs);
+        int next = kTraversalDone;
+        if (nt.hit[3]) next = refs.w;
+        if (nt.hit[2]) {
+          if (next != kTraversalDone) stk.push(sp, next);
+          next = refs.z;
+        }
+        if (nt.hit[1]) {
+          if (next != kTraversalDone) stk.push(sp, next);
+          next = refs.y;
+        }
+        if (nt.hit[0]) {
+          if (next != kTraversalDone) stk.push(sp, next);
+          next = refs.x;
+        }
+        cur = next != kTraversalDone ? next : (sp == 0 ? kTraversalDone : stk.pop(sp));
+      }
+      while (cur < 0 && cur != kTraversalDone) {
+        hit = hit || leaf_any(g, ~(uint32_t)cur, o, d, eps, tfar);
+        cur = (hit || sp == 0) ? kTraversalDone : stk.pop(sp);
       }
     }
-    while (cur < 0 && cur != kTraversalDone) {
-      uint32_t v = ~(uint32_t)cur;
-      uint32_t first = v >> 3, cnt = (v & 7u) + 1u;
-      for (uint32_t k = 0; k < cnt; k++) {
-        uint32_t slot = first + k;
-        float4 A = g.tri0[slot], B = g.tri1[slot], C = g.tri2[slot];
-        float t = tri_intersect(mk3(A.x, A.y, A.z), mk3(B.x, B.y, B.z), mk3(C.x, C.y, C.z), o, d);
-        if (eps < t && t < tfar) hit = true;
+  } else {
+    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    while (cur != kTraversalDone) {
+      while (cur >= 0) {
+        const float4* nd = g.nodes + 4 * (size_t)cur;
+        float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+        float tn0, tn1;
+        bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, o, inv, tfar, tn0);
+        bool h1 = slab(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, o, inv, tfar, tn1);
+        int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+        if (h0 && h1) {
+          stk.push(sp, c1);
+          cur = c0;
+        } else if (h0) {
+          cur = c0;
+        } else if (h1) {
+          cur = c1;
+        } else {
+          cur = sp == 0 ? kTraversalDone : stk.pop(sp);
+        }
       }
-      if (hit || sp == 0) {
-        cur = kTraversalDone;
-      } else {
-        sp--;
-        cur = stk[sp * stride];
+      while (cur < 0 && cur != kTraversalDone) {
+        hit = hit || leaf_any(g, ~(uint32_t)cur, o, d, eps, tfar);
+        cur = (hit || sp == 0) ? kTraversalDone : stk.pop(sp);
       }
     }
   }
@@ -370,11 +507,12 @@ __device__ __forceinline__ bool mesh_any(const SceneDev& sc, const Geom& g, f3 o
 // Scene::castRay, reference Scene.h:144-189: mesh first, then the spheres in
 // order (the first of equal t wins); the sphere wins only when strictly closer
 // than the mesh hit.  Returns t and an id: kMiss, kSphereBit|index, or triangle slot.
-__device__ __forceinline__ void cast_ray(const SceneDev& sc, const Geom& g, f3 o, f3 d, int* stk,
-                                         int stride, float& t_out, uint32_t& id_out) {
+template <int MODE>
+__device__ __forceinline__ void cast_ray(const SceneDev& sc, const Geom& g, f3 o, f3 d, const Stack& stk,
+                                         float& t_out, uint32_t& id_out) {
   float tfar;
   uint32_t slot;
-  mesh_closest(sc, g, o, d, stk, stride, tfar, slot);
+  mesh_closest<MODE>(sc, g, o, d, stk, tfar, slot);
   float ts = INFINITY;
   uint32_t si = 0;
   for (uint32_t i = 0; i < sc.num_spheres; i++) {
@@ -413,8 +551,9 @@ __device__ __forceinline__ void cast_ray(const SceneDev& sc, const Geom& g, f3 o
 
 // Scene::isOccluded, reference Scene.h:191-225, for a segment whose far end
 // tfar = distance - eps has been computed by the caller (distance >= 2 eps).
+template <int MODE>
 __device__ __forceinline__ bool occluded(const SceneDev& sc, const Geom& g, f3 o, f3 d, float tfar,
-                                         int* stk, int stride) {
+                                         const Stack& stk) {
   for (uint32_t i = 0; i < sc.num_spheres; i++) {
     float4 s = sc.sph0[i];
     float t = sphere_intersect(mk3(s.x, s.y, s.z), s.w, o, d, sc.eps);
@@ -430,7 +569,7 @@ __device__ __forceinline__ bool occluded(const SceneDev& sc, const Geom& g, f3 o
     float t = plane_intersect(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), o, d);
     if (t > sc.eps && t < tfar) return true;
   }
-  return mesh_any(sc, g, o, d, tfar, stk, stride);
+  return mesh_any<MODE>(sc, g, o, d, tfar, stk);
 }
 
 // Surface normal and material of a hit (reference Scene.h:169-171,181-187;
@@ -875,19 +1014,30 @@ __global__ __launch_bounds__(256) void k_generate(Queue q, const SegCounter* seg
   if (use_depth) q.depth[slot] = 0;
 }
 
-// Dynamic LDS of the traversal kernels: the per-lane stacks (stack_entries x
-// BLOCK ints), then, when LDS_SCENE, the staged BVH and triangles.
-#define RTX_TRACE_PROLOGUE()                                                          \
-  extern __shared__ float4 lds_dyn[];                                                 \
-  int* const stk = reinterpret_cast<int*>(lds_dyn) + threadIdx.x;                     \
-  const Geom geom = LDS_SCENE ? stage_geom_lds(sc, lds_dyn + (stack_entries * BLOCK) / 4, \
-                                               threadIdx.x, BLOCK)                    \
-                              : global_geom(sc)
+// Dynamic LDS of the traversal kernels: the per-lane stacks (lds_entries x BLOCK
+// ints), then, in kLdsBvh2 mode, the staged BVH and triangles.  `tp` carries the
+// stack geometry; the spill column of a thread is indexed by its position in the launch.
+struct TraceParams {
+  int lds_entries;        // stack entries kept in LDS
+  int* spill;             // deeper entries: spill[(entry - lds_entries) * spill_stride + thread]
+  uint32_t spill_stride;  // >= threads per launch
+};
+#define RTX_TRACE_PROLOGUE()                                                                  \
+  extern __shared__ float4 lds_dyn[];                                                         \
+  Stack stk;                                                                                  \
+  stk.lds = reinterpret_cast<int*>(lds_dyn) + threadIdx.x;                                    \
+  stk.stride = BLOCK;                                                                         \
+  stk.lds_entries = tp.lds_entries;                                                           \
+  stk.spill_stride = tp.spill_stride;                                                         \
+  stk.spill = tp.spill + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * BLOCK + threadIdx.x); \
+  const Geom geom = MODE == kLdsBvh2 ? stage_geom_lds(sc, lds_dyn + (tp.lds_entries * BLOCK) / 4, \
+                                                      threadIdx.x, BLOCK)                     \
+                                     : global_geom(sc)
 
-template <int BLOCK, bool LDS_SCENE>
+template <int BLOCK, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_intersect(SceneDev sc, Queue q, uint2* hits,
                                                      const SegCounter* seg, int qi, uint32_t cap,
-                                                     int stack_entries) {
+                                                     TraceParams tp) {
   const uint32_t s = blockIdx.y;
   const uint32_t n = seg_paths(seg[s].c[qi]);
   if (blockIdx.x * BLOCK >= n) return;  // the whole block is beyond the fill: skip the staging too
@@ -915,7 +1065,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(SceneDev sc, Queue q, uint2
     }
     float t;
     uint32_t id;
-    cast_ray(sc, geom, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), stk, BLOCK, t, id);
+    cast_ray<MODE>(sc, geom, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), stk, t, id);
     hits[i] = make_uint2(__float_as_uint(t), id);
     a = an;
     b = bn;
@@ -957,10 +1107,10 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, Queue in, Queue out,
 
 // Traces the NEE segments queued by k_shade; an unoccluded one adds its
 // contribution to the colour of the path it belongs to (Integrator.h:217-223).
-template <int BLOCK, bool LDS_SCENE>
+template <int BLOCK, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_shadow(SceneDev sc, Queue paths, ShadowQueue sq,
                                                   const SegCounter* seg, int q_out, uint32_t cap,
-                                                  int stack_entries) {
+                                                  TraceParams tp) {
   const uint32_t s = blockIdx.y;
   const uint32_t n = seg_shadow(seg[s].c[q_out]);
   if (blockIdx.x * BLOCK >= n) return;
@@ -971,7 +1121,7 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(SceneDev sc, Queue paths, Shad
     float4 b = sq.q1[k];
     const uint32_t slot = __float_as_uint(b.w);
     float4 r0 = paths.r0[slot];
-    bool occ = occluded(sc, geom, mk3(r0.x, r0.y, r0.z), mk3(a.x, a.y, a.z), a.w, stk, BLOCK);
+    bool occ = occluded<MODE>(sc, geom, mk3(r0.x, r0.y, r0.z), mk3(a.x, a.y, a.z), a.w, stk);
     if (!occ) {
       float4 s1 = paths.s1[slot];
       s1.x += b.x;
@@ -987,10 +1137,10 @@ __global__ __launch_bounds__(BLOCK) void k_shadow(SceneDev sc, Queue paths, Shad
 // kernels is all launch latency.  Every lane leaves after at most kFinishCap
 // bounces (a path that long has probability below 0.99^65536).
 constexpr uint32_t kFinishCap = 65536;
-template <int BLOCK, bool LDS_SCENE>
+template <int BLOCK, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_finish(SceneDev sc, Queue q, const SegCounter* seg, int qi,
                                                   uint32_t cap, float* res, Summary* sum,
-                                                  int stack_entries) {
+                                                  TraceParams tp) {
   RTX_TRACE_PROLOGUE();
   const uint32_t s = blockIdx.y;
   const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
@@ -1002,7 +1152,7 @@ __global__ __launch_bounds__(BLOCK) void k_finish(SceneDev sc, Queue q, const Se
     for (uint32_t it = 0; it < kFinishCap; it++) {
       float t;
       uint32_t id;
-      cast_ray(sc, geom, p.o, p.d, stk, BLOCK, t, id);
+      cast_ray<MODE>(sc, geom, p.o, p.d, stk, t, id);
       nb++;
       bool want_shadow, did_nee;
       ShadowReq sr;
@@ -1010,7 +1160,7 @@ __global__ __launch_bounds__(BLOCK) void k_finish(SceneDev sc, Queue q, const Se
       nn += did_nee ? 1u : 0u;
       if (want_shadow) {
         ns++;
-        if (!occluded(sc, geom, p.o, sr.d, sr.tfar, stk, BLOCK)) p.col = vadd(p.col, sr.contrib);
+        if (!occluded<MODE>(sc, geom, p.o, sr.d, sr.tfar, stk)) p.col = vadd(p.col, sr.contrib);
       }
       if (!alive) break;
     }
@@ -1064,10 +1214,10 @@ __global__ __launch_bounds__(256) void k_reduce(const float* res, float* accum, 
 // ----------------------------------------------------------------------------
 // Fixed-ray-set kernels (parity entry points).
 
-template <int BLOCK, bool LDS_SCENE>
+template <int BLOCK, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_trace_closest(SceneDev sc, const float* rays, uint32_t n,
                                                          uint32_t* kind, uint32_t* prim, float* t_out,
-                                                         float* normal, int stack_entries) {
+                                                         float* normal, TraceParams tp) {
   RTX_TRACE_PROLOGUE();
   uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
@@ -1075,7 +1225,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest(SceneDev sc, const floa
   f3 d = mk3(rays[6 * (size_t)i + 3], rays[6 * (size_t)i + 4], rays[6 * (size_t)i + 5]);
   float t;
   uint32_t id;
-  cast_ray(sc, geom, o, d, stk, BLOCK, t, id);
+  cast_ray<MODE>(sc, geom, o, d, stk, t, id);
   f3 n3 = mk3(0, 0, 0);
   if (id == kMiss) {
     kind[i] = 0;
@@ -1110,10 +1260,10 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest(SceneDev sc, const floa
   }
 }
 
-template <int BLOCK, bool LDS_SCENE>
+template <int BLOCK, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_trace_occluded(SceneDev sc, const float* rays,
                                                           const float* dist, uint32_t n, uint8_t* out,
-                                                          int stack_entries) {
+                                                          TraceParams tp) {
   RTX_TRACE_PROLOGUE();
   uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
   if (i >= n) return;
@@ -1122,7 +1272,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_occluded(SceneDev sc, const flo
   float distance = dist[i];
   bool occ = false;
   if (!(distance < 2.0f * sc.eps))  // Scene.h:192-194
-    occ = occluded(sc, geom, o, d, distance - sc.eps, stk, BLOCK);
+    occ = occluded<MODE>(sc, geom, o, d, distance - sc.eps, stk);
   out[i] = occ ? 1 : 0;
 }
 

@@ -46,6 +46,7 @@ constexpr uint32_t kSegmentTarget = 8192;        // aim for this many slots per 
 constexpr uint32_t kMaxSegments = 512;
 constexpr int kTraceBlock = 128;                 // threads per block of the traversal kernels
 constexpr size_t kLdsSceneMaxBytes = 16 * 1024;  // stage BVH + triangles in LDS up to this size
+constexpr int kWideLdsStack = 16;                // LDS stack entries per lane for the four-child tree
 constexpr int kFinishBlock = 64;
 constexpr uint32_t kTraceBatches = 2;  // ray batches per block of k_intersect/k_shadow (the next batch's loads overlap the current traversal)
 constexpr int kPollSlots = 4;
@@ -93,9 +94,10 @@ struct rtx_ctx {
   DevBuf<int> mat1, sph2;
   rtx::SceneDev scene{};
   rtx_scene_info info{};
-  int stack_entries = 8;
-  bool lds_scene = false;   // BVH + triangles small enough to be staged in LDS by every block
-  size_t lds_scene_bytes = 0;
+  int stack_entries = 8;    // stack entries per lane kept in LDS
+  int trace_mode = rtx::kGlobalBvh2;
+  size_t lds_scene_bytes = 0;  // kLdsBvh2: bytes of BVH + triangles every block stages
+  DevBuf<int> spill;           // stack entries beyond stack_entries, one column per launched thread
 
   // path pool
   DevBuf<float4> r0[2], s0[2], s1[2], sq0, sq1;
@@ -161,7 +163,7 @@ void free_ctx(rtx_ctx* c) {
     c->r0[i].release(); c->r1[i].release(); c->s0[i].release(); c->s1[i].release();
     c->s2[i].release(); c->depth[i].release();
   }
-  c->sq0.release(); c->sq1.release(); c->hits.release(); c->seg.release(); c->sum.release();
+  c->sq0.release(); c->sq1.release(); c->hits.release(); c->seg.release(); c->sum.release(); c->spill.release();
   c->resolve_tmp.release(); c->res.release();
   if (c->h_sum) (void)hipHostFree(c->h_sum);
   for (int i = 0; i < kPollSlots; i++)
@@ -286,11 +288,22 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
   auto t_begin = std::chrono::steady_clock::now();
   // Small scenes are staged in LDS by every block and get 2-triangle leaves; with
   // those a scene of n triangles has about n/2 inner nodes of 64 bytes.
+  // Larger scenes stream their nodes from L2/HBM: four-child quantised nodes (two levels per
+  // 64-byte fetch) and 4-triangle leaves.
   const bool small_scene = s->num_triangles > 0 && s->num_triangles * (48 + 32 + 8) <= kLdsSceneMaxBytes;
   rtx::FlatBvh bvh;
-  rtx::build_bvh(s->triangles, s->num_triangles, small_scene ? 2u : 4u, bvh);
-  int stack_entries = pick_stack_entries(bvh.max_depth);
-  if (stack_entries < 0) return fail(RTX_ERR_UNSUPPORTED, "rtx_set_scene: BVH too deep");
+  rtx::build_bvh(s->triangles, s->num_triangles, small_scene ? 2u : 4u, small_scene ? 2u : 4u, bvh);
+  // Stack: two-child trees keep all of it in LDS; the wide tree keeps kWideLdsStack entries
+  // there and spills deeper ones (rare) to a global column per thread.
+  int stack_entries;
+  size_t spill_entries = 0;
+  if (bvh.width == 4) {
+    stack_entries = kWideLdsStack;
+    if (bvh.max_stack + 1 > (uint32_t)kWideLdsStack) spill_entries = bvh.max_stack + 1 - kWideLdsStack;
+  } else {
+    stack_entries = pick_stack_entries(bvh.max_stack);
+    if (stack_entries < 0) return fail(RTX_ERR_UNSUPPORTED, "rtx_set_scene: BVH too deep");
+  }
 
   const size_t nt = s->num_triangles;
   std::vector<float4> nodes(bvh.nodes.size() / 4), t0(nt), t1(nt), t2(nt);
@@ -362,6 +375,7 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
   }
 
   HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(c->spill.alloc(spill_entries * (size_t)c->pool));
   HIP_TRY(c->nodes.upload(nodes));
   HIP_TRY(c->tri0.upload(t0));
   HIP_TRY(c->tri1.upload(t1));
@@ -400,7 +414,12 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
   d.integrator = c->cfg.integrator;
   c->stack_entries = stack_entries;
   c->lds_scene_bytes = (nodes.size() + 3 * nt) * sizeof(float4);
-  c->lds_scene = nt > 0 && c->lds_scene_bytes <= kLdsSceneMaxBytes;
+  if (bvh.width == 4)
+    c->trace_mode = rtx::kGlobalBvh4;
+  else if (nt > 0 && c->lds_scene_bytes <= kLdsSceneMaxBytes)
+    c->trace_mode = rtx::kLdsBvh2;
+  else
+    c->trace_mode = rtx::kGlobalBvh2;
   c->have_scene = true;
   c->info.num_nodes = d.num_nodes;
   c->info.num_triangles = d.num_tris;
@@ -408,6 +427,8 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
   c->info.num_spheres = d.num_spheres;
   c->info.max_depth = bvh.max_depth;
   c->info.stack_entries = (uint32_t)stack_entries;
+  c->info.bvh_width = bvh.width;
+  c->info.stack_bound = bvh.max_stack;
   c->info.build_ms =
       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   return RTX_OK;
@@ -421,6 +442,19 @@ int rtx_get_scene_info(rtx_ctx* c, rtx_scene_info* out) {
 }
 
 }  // extern "C"
+
+// Launches kernel<BLOCK, mode> for the context's traversal mode.
+#define RTX_LAUNCH(K, B, M, CFG, ARGS) hipLaunchKernelGGL((K<B, M>), RTX_UNPACK CFG, RTX_UNPACK ARGS)
+#define RTX_UNPACK(...) __VA_ARGS__
+#define RTX_BY_MODE(mode, K, B, CFG, ARGS)                                   \
+  do {                                                                       \
+    if ((mode) == rtx::kLdsBvh2)                                             \
+      RTX_LAUNCH(K, B, rtx::kLdsBvh2, CFG, ARGS);                            \
+    else if ((mode) == rtx::kGlobalBvh4)                                     \
+      RTX_LAUNCH(K, B, rtx::kGlobalBvh4, CFG, ARGS);                         \
+    else                                                                     \
+      RTX_LAUNCH(K, B, rtx::kGlobalBvh2, CFG, ARGS);                         \
+  } while (0)
 
 namespace {
 
@@ -469,10 +503,10 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
   rtx::Summary* sum = c->sum.p;
   rtx::ShadowQueue sq{c->sq0.p, c->sq1.p};
   const int use_depth = c->cfg.max_bounces ? 1 : 0;
-  const size_t scene_lds = c->lds_scene ? c->lds_scene_bytes : 0;
+  const size_t scene_lds = c->trace_mode == rtx::kLdsBvh2 ? c->lds_scene_bytes : 0;
   const size_t lds = (size_t)c->stack_entries * kTraceBlock * sizeof(int) + scene_lds;
   const size_t lds_fin = (size_t)c->stack_entries * kFinishBlock * sizeof(int) + scene_lds;
-  const int se = c->stack_entries;
+  const rtx::TraceParams tp{c->stack_entries, c->spill.p, pool};
   const bool shadows = c->scene.num_lights != 0 && c->cfg.integrator == 0;
   LaunchTimer lt(c, st, timer);
   uint64_t launches = 0, iterations = 0;
@@ -507,12 +541,9 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
     if (left_upper == 0 && active_upper == 0) break;
     if (left_upper == 0 && active_upper <= c->finish_paths) {
       lt.begin(kFinish, active_upper);
-      if (c->lds_scene)
-        rtx::k_finish<kFinishBlock, true><<<dim3(div_up(seg_max_upper, kFinishBlock), nseg), kFinishBlock, lds_fin, st>>>(
-            c->scene, queue_of(c, cur), seg, cur, cap, c->res.p, sum, se);
-      else
-        rtx::k_finish<kFinishBlock, false><<<dim3(div_up(seg_max_upper, kFinishBlock), nseg), kFinishBlock, lds_fin, st>>>(
-            c->scene, queue_of(c, cur), seg, cur, cap, c->res.p, sum, se);
+      RTX_BY_MODE(c->trace_mode, rtx::k_finish, kFinishBlock,
+                  (dim3(div_up(seg_max_upper, kFinishBlock), nseg), kFinishBlock, lds_fin, st),
+                  (c->scene, queue_of(c, cur), seg, cur, cap, c->res.p, sum, tp));
       lt.end();
       launches++;
       finished = true;
@@ -525,10 +556,8 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
     gx128 = std::max(1u, std::min(gx128, div_up(gx128, kTraceBatches)));
     const uint32_t gx256 = div_up(seg_max_upper, 256);
     lt.begin(kIsect, active_upper);
-    if (c->lds_scene)
-      rtx::k_intersect<kTraceBlock, true><<<dim3(gx128, nseg), kTraceBlock, lds, st>>>(c->scene, qc, c->hits.p, seg, cur, cap, se);
-    else
-      rtx::k_intersect<kTraceBlock, false><<<dim3(gx128, nseg), kTraceBlock, lds, st>>>(c->scene, qc, c->hits.p, seg, cur, cap, se);
+    RTX_BY_MODE(c->trace_mode, rtx::k_intersect, kTraceBlock, (dim3(gx128, nseg), kTraceBlock, lds, st),
+                (c->scene, qc, c->hits.p, seg, cur, cap, tp));
     lt.end();
     lt.begin(kShade, active_upper);
     rtx::k_shade<<<dim3(gx256, nseg), 256, 0, st>>>(c->scene, qc, qn, sq, c->hits.p, seg, cur, cap, c->res.p);
@@ -536,10 +565,8 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
     launches += 2;
     if (shadows) {
       lt.begin(kShadow, active_upper);
-      if (c->lds_scene)
-        rtx::k_shadow<kTraceBlock, true><<<dim3(gx128, nseg), kTraceBlock, lds, st>>>(c->scene, qn, sq, seg, nxt, cap, se);
-      else
-        rtx::k_shadow<kTraceBlock, false><<<dim3(gx128, nseg), kTraceBlock, lds, st>>>(c->scene, qn, sq, seg, nxt, cap, se);
+      RTX_BY_MODE(c->trace_mode, rtx::k_shadow, kTraceBlock, (dim3(gx128, nseg), kTraceBlock, lds, st),
+                  (c->scene, qn, sq, seg, nxt, cap, tp));
       lt.end();
       launches++;
     }
@@ -739,13 +766,15 @@ int rtx_trace_closest(rtx_ctx* c, const float* rays_host, size_t n, uint32_t* ki
     TRY_BREAK(prim.alloc(n));
     if (normal_out) TRY_BREAK(nrm.alloc(n * 3));
     TRY_BREAK(hipMemcpy(rays.p, rays_host, n * 6 * sizeof(float), hipMemcpyHostToDevice));
-    size_t lds = (size_t)c->stack_entries * kTraceBlock * sizeof(int) + (c->lds_scene ? c->lds_scene_bytes : 0);
-    if (c->lds_scene)
-      rtx::k_trace_closest<kTraceBlock, true><<<div_up((uint32_t)n, kTraceBlock), kTraceBlock, lds, 0>>>(
-          c->scene, rays.p, (uint32_t)n, kind.p, prim.p, t.p, nrm.p, c->stack_entries);
-    else
-      rtx::k_trace_closest<kTraceBlock, false><<<div_up((uint32_t)n, kTraceBlock), kTraceBlock, lds, 0>>>(
-          c->scene, rays.p, (uint32_t)n, kind.p, prim.p, t.p, nrm.p, c->stack_entries);
+    size_t lds = (size_t)c->stack_entries * kTraceBlock * sizeof(int) +
+                 (c->trace_mode == rtx::kLdsBvh2 ? c->lds_scene_bytes : 0);
+    const rtx::TraceParams tp{c->stack_entries, c->spill.p, c->pool};
+    for (size_t first = 0; first < n; first += c->pool) {  // at most pool rays per launch (spill columns)
+      const uint32_t m = (uint32_t)std::min<size_t>(c->pool, n - first);
+      RTX_BY_MODE(c->trace_mode, rtx::k_trace_closest, kTraceBlock, (div_up(m, kTraceBlock), kTraceBlock, lds, 0),
+                  (c->scene, rays.p + 6 * first, m, kind.p + first, prim.p + first, t.p + first,
+                   nrm.p ? nrm.p + 3 * first : nullptr, tp));
+    }
     TRY_BREAK(hipGetLastError());
     TRY_BREAK(hipDeviceSynchronize());
     TRY_BREAK(hipMemcpy(kind_out, kind.p, n * 4, hipMemcpyDeviceToHost));
@@ -775,13 +804,14 @@ int rtx_trace_occluded(rtx_ctx* c, const float* rays_host, const float* distance
     TRY_BREAK(occ.alloc(n));
     TRY_BREAK(hipMemcpy(rays.p, rays_host, n * 6 * sizeof(float), hipMemcpyHostToDevice));
     TRY_BREAK(hipMemcpy(dist.p, distance_host, n * sizeof(float), hipMemcpyHostToDevice));
-    size_t lds = (size_t)c->stack_entries * kTraceBlock * sizeof(int) + (c->lds_scene ? c->lds_scene_bytes : 0);
-    if (c->lds_scene)
-      rtx::k_trace_occluded<kTraceBlock, true><<<div_up((uint32_t)n, kTraceBlock), kTraceBlock, lds, 0>>>(
-          c->scene, rays.p, dist.p, (uint32_t)n, occ.p, c->stack_entries);
-    else
-      rtx::k_trace_occluded<kTraceBlock, false><<<div_up((uint32_t)n, kTraceBlock), kTraceBlock, lds, 0>>>(
-          c->scene, rays.p, dist.p, (uint32_t)n, occ.p, c->stack_entries);
+    size_t lds = (size_t)c->stack_entries * kTraceBlock * sizeof(int) +
+                 (c->trace_mode == rtx::kLdsBvh2 ? c->lds_scene_bytes : 0);
+    const rtx::TraceParams tp{c->stack_entries, c->spill.p, c->pool};
+    for (size_t first = 0; first < n; first += c->pool) {
+      const uint32_t m = (uint32_t)std::min<size_t>(c->pool, n - first);
+      RTX_BY_MODE(c->trace_mode, rtx::k_trace_occluded, kTraceBlock, (div_up(m, kTraceBlock), kTraceBlock, lds, 0),
+                  (c->scene, rays.p + 6 * first, dist.p + first, m, occ.p + first, tp));
+    }
     TRY_BREAK(hipGetLastError());
     TRY_BREAK(hipDeviceSynchronize());
     TRY_BREAK(hipMemcpy(occluded_out, occ.p, n, hipMemcpyDeviceToHost));

@@ -22,17 +22,21 @@ def probe(tmp_path_factory):
                            os.path.join(ROOT, "tests", "native", "bvh_probe.cpp"),
                            os.path.join(src, "bvh_build.cpp"), "-o", str(out)])
     lib = C.CDLL(str(out))
-    lib.bvh_probe.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.bvh_probe.argtypes = [C.c_void_p, C.c_size_t, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return lib
 
 
-def build(probe, tris, max_leaf=4):
+def build(probe, tris, max_leaf=4, width=2, want_stack=False):
     tris = np.ascontiguousarray(tris, np.float32).reshape(-1, 9)
-    n = probe.bvh_probe(tris.ctypes.data, len(tris), max_leaf, None, None, None)
+    n = probe.bvh_probe(tris.ctypes.data, len(tris), max_leaf, width, None, None, None, None)
     nodes = np.zeros((n, 16), np.float32)
     order = np.zeros(len(tris), np.uint32)
     depth = C.c_uint32()
-    probe.bvh_probe(tris.ctypes.data, len(tris), max_leaf, nodes.ctypes.data, order.ctypes.data, C.byref(depth))
+    stack = C.c_uint32()
+    probe.bvh_probe(tris.ctypes.data, len(tris), max_leaf, width, nodes.ctypes.data, order.ctypes.data,
+                    C.byref(depth), C.byref(stack))
+    if want_stack:
+        return nodes, order, depth.value, stack.value
     return nodes, order, depth.value
 
 
@@ -86,7 +90,8 @@ def test_flat_bvh_structure(name, make, max_leaf, probe):
 
 
 def test_empty_mesh_has_no_nodes(probe):
-    assert probe.bvh_probe(None, 0, 4, None, None, None) == 0
+    assert probe.bvh_probe(None, 0, 4, 2, None, None, None, None) == 0
+    assert probe.bvh_probe(None, 0, 4, 4, None, None, None, None) == 0
 
 
 def test_flat_bvh_walk_equals_linear_scan(probe, oracle):
@@ -129,3 +134,66 @@ def test_flat_bvh_walk_equals_linear_scan(probe, oracle):
             assert best_p == -1
         else:
             assert best_p == wp and best_t == wt
+
+
+def decode4(node):
+    """(lo[4,3], hi[4,3], refs[4]) of a four-child quantised node (format: bvh_build.h)."""
+    u = node.view(np.uint32)
+    origin = node[0:3].astype(np.float32)
+    ew = int(u[3])
+    scale = np.array([np.array([((ew >> (8 * k)) & 0xFF) << 23], np.uint32).view(np.float32)[0] for k in range(3)],
+                     np.float32)
+    lo_w, hi_w = u[4:7], u[7:10]
+    lo = np.zeros((4, 3), np.float32)
+    hi = np.zeros((4, 3), np.float32)
+    for c in range(4):
+        for k in range(3):
+            lo[c, k] = origin[k] + np.float32((int(lo_w[k]) >> (8 * c)) & 0xFF) * scale[k]
+            hi[c, k] = origin[k] + np.float32((int(hi_w[k]) >> (8 * c)) & 0xFF) * scale[k]
+    return lo, hi, node[12:16].view(np.int32)
+
+
+@pytest.mark.parametrize("name,make", [("soup", lambda: scenes.soup(3000, 0).triangles),
+                                       ("terrain", lambda: scenes.terrain(24).triangles),
+                                       ("cornell", lambda: scenes.cornell().triangles),
+                                       ("five", lambda: scenes.cornell().triangles[:5])])
+def test_wide_bvh_structure(name, make, probe):
+    """Four-child quantised tree: every triangle in exactly one leaf, decoded child boxes contain
+    their triangles (and their own children's decoded boxes), absent children are inverted boxes,
+    the stack bound is 3 entries per level."""
+    tris = make()
+    nodes, order, depth, stack = build(probe, tris, 4, 4, want_stack=True)
+    assert sorted(order.tolist()) == list(range(len(tris)))
+    assert stack == 3 * depth
+    seen = np.zeros(len(order), np.int32)
+    info = {"maxd": 0}
+
+    def visit(i, d):
+        """Returns the bounds of the triangles under node i; checks every decoded child box."""
+        info["maxd"] = max(info["maxd"], d)
+        lo, hi, refs = decode4(nodes[i])
+        tlo, thi = np.full(3, np.inf), np.full(3, -np.inf)
+        nkids = 0
+        for c in range(4):
+            r = int(refs[c])
+            if r == -2**31:
+                assert np.all(lo[c] > hi[c])          # absent child: lo byte 255, hi byte 0
+                continue
+            nkids += 1
+            if r >= 0:
+                clo, chi = visit(r, d + 1)
+            else:
+                v = ~r
+                first, cnt = v >> 3, (v & 7) + 1
+                assert cnt <= 4
+                seen[first:first + cnt] += 1
+                pts = tris[order[first:first + cnt]].reshape(-1, 3)
+                clo, chi = pts.min(0), pts.max(0)
+            # the decoded (quantised, outward-rounded) box contains everything beneath the child
+            assert np.all(clo >= lo[c]) and np.all(chi <= hi[c])
+            tlo, thi = np.minimum(tlo, clo), np.maximum(thi, chi)
+        assert nkids >= 2
+        return tlo, thi
+
+    visit(0, 1)
+    assert np.all(seen == 1) and info["maxd"] == depth
