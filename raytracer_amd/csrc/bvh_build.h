@@ -40,9 +40,8 @@ struct FlatBvh {
 };
 
 // tris: ntri*9 floats (a,b,c).  max_leaf (1..8): a node with more triangles is
-// always split.  A box test costs about a third of a triangle test, so scenes
-// that are staged in LDS (instruction-bound) use 2; scenes whose nodes stream
-// from L2/HBM (bandwidth-bound) use 4, which halves the node count.  Boxes are padded by a few 1e-6 relative so that
+// always split.  A box test costs about a third of a triangle test; the library
+// uses 2 for every scene.  Boxes are padded by a few 1e-6 relative so that
 // a hit accepted by the float triangle test is never culled by rounding in the
 // slab test.  Deterministic for a given input.
 void build_bvh(const float* tris, size_t ntri, uint32_t max_leaf, uint32_t width, FlatBvh& out);

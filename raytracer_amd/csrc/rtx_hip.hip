@@ -289,10 +289,11 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
   // Small scenes are staged in LDS by every block and get 2-triangle leaves; with
   // those a scene of n triangles has about n/2 inner nodes of 64 bytes.
   // Larger scenes stream their nodes from L2/HBM: four-child quantised nodes (two levels per
-  // 64-byte fetch) and 4-triangle leaves.
+  // 64-byte fetch).  Leaves hold at most 2 triangles in both forms (a box test costs about a
+  // third of a triangle test; measured best on the 1M-triangle mesh as well).
   const bool small_scene = s->num_triangles > 0 && s->num_triangles * (48 + 32 + 8) <= kLdsSceneMaxBytes;
   rtx::FlatBvh bvh;
-  rtx::build_bvh(s->triangles, s->num_triangles, small_scene ? 2u : 4u, small_scene ? 2u : 4u, bvh);
+  rtx::build_bvh(s->triangles, s->num_triangles, 2u, small_scene ? 2u : 4u, bvh);
   // Stack: two-child trees keep all of it in LDS; the wide tree keeps kWideLdsStack entries
   // there and spills deeper ones (rare) to a global column per thread.
   int stack_entries;
