@@ -6,6 +6,12 @@ unchanged into oracle/_ref/libref_pcg.so by oracle/Makefile):
 
 pcg_kat.json        rand_pcg / Uniform / pcg_hash sequences from the REFERENCE build
                     (this pins the oracle's generator to the reference).
+functions.npz       camera rays on a 64x64 grid (800^2 and 1024^2, three cameras) and per-function
+                    vectors (rotMatrixVectors, cosineSampleHemisphere, Triangle::samplePoint,
+                    schlickApprox, skyEmission, box/plane/sphere/triangle intersect) from the
+                    oracle.  Regression vectors of the restatement: parity unpinned.
+image_*.npz         128x128 images of the oracle at IMAGE_SPP samples per pixel (sums / spp),
+                    seed 0x5EED, with the bounce count.  Regression vectors as well.
 closest_*.npz       fixed ray sets with (kind, prim, t) from the oracle's first-party
                     linear scan.  These are regression vectors of the restatement, not
                     outputs of the reference (which cannot be built here): parity unpinned.
@@ -55,7 +61,68 @@ def closest():
                             prim=prim, t_bits=t.view(np.uint32), dist=dist, occluded=occ)
 
 
+def functions():
+    rng = np.random.default_rng(77)
+    out = {}
+    for res in (800, 1024):
+        for cam, fov in ((0, 50.0), (1, 60.0), (2, 50.0)):
+            cfg = Config(width=res, height=res, camera=cam, fov=fov)
+            grid = [(x, y) for y in np.linspace(0.5, res - 0.5, 64) for x in np.linspace(0.5, res - 0.5, 64)]
+            rays = np.array([np.concatenate(orc.camera_ray(cfg, x, y, state=int(i) * 2654435761 % 2**32)[:2])
+                             for i, (x, y) in enumerate(grid)], np.float32)
+            out[f"camera{cam}_{res}"] = rays
+    n = rng.normal(size=(1000, 3)).astype(np.float32)
+    n /= np.linalg.norm(n, axis=1, keepdims=True).astype(np.float32)
+    out["rot_normals"] = n
+    out["rot_matrices"] = np.array([orc.rot_matrix_vectors(v, (0, 0, 1)) for v in n], np.float32)
+    states = rng.integers(0, 2**32, 512, dtype=np.uint64).astype(np.uint32)
+    out["rng_states"] = states
+    out["cosine_dirs"] = np.array([orc.cosine_sample_hemisphere(int(s))[0] for s in states], np.float32)
+    tri = rng.uniform(-2, 2, (512, 9)).astype(np.float32)
+    out["sample_tris"] = tri
+    sp = [orc.triangle_sample_point(t[0:3], t[3:6], t[6:9], int(s)) for t, s in zip(tri, states)]
+    out["sample_points"] = np.array([np.concatenate([x[0], x[1], [x[2]]]) for x in sp], np.float32)  # point, n, rcp_area
+    cos = np.linspace(0, 1, 257, dtype=np.float32)
+    out["schlick_cos"] = cos
+    out["schlick"] = np.array([[orc.lib().orc_schlick(r, float(c)) for c in cos] for r in (0.5, 2.0)], np.float32)
+    d = rng.normal(size=(512, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    out["sky_dirs"] = d
+    out["sky"] = np.array([orc.sky_emission(v) for v in d], np.float32)
+    o = rng.uniform(-3, 3, (512, 3)).astype(np.float32)
+    out["isect_o"], out["isect_d"] = o, d
+    out["isect_tri"] = np.array([orc.triangle_intersect(t[0:3], t[3:6], t[6:9], a, b)
+                                 for t, a, b in zip(tri, o, d)], np.float32).view(np.uint32)
+    out["isect_sphere"] = np.array([orc.sphere_intersect((0.1, -0.2, 0.3), 1.5, a, b)
+                                    for a, b in zip(o, d)], np.float32).view(np.uint32)
+    out["isect_box"] = np.array([orc.box_intersect((-1, -0.5, -1.5), (1, 0.75, 0.5), a, b)
+                                 for a, b in zip(o, d)], np.float32).view(np.uint32)
+    out["isect_plane"] = np.array([orc.plane_intersect((0, -1, 0), (0, 1, 0), a, b)
+                                   for a, b in zip(o, d)], np.float32).view(np.uint32)
+    np.savez_compressed(os.path.join(HERE, "functions.npz"), **out)
+
+
+IMAGE_SPP = 1024
+IMAGES = {
+    "cornell": (lambda: scenes.cornell(), 0),
+    "cornell_4lights": (lambda: scenes.cornell(lights=4), 0),
+    "sample1": (lambda: scenes.sphere_sky(), 1),
+    "sample2": (lambda: scenes.sphere_sky(glass=True), 1),
+    "ref_scene0": (lambda: scenes.reference_scene(0), 1),
+}
+
+
+def images():
+    for name, (make, sky) in IMAGES.items():
+        cfg = Config(width=128, height=128, sky=sky)
+        img, st = orc.OracleScene(make(), cfg).render(IMAGE_SPP, seed=0x5EED)
+        np.savez_compressed(os.path.join(HERE, f"image_{name}.npz"), mean=(img / IMAGE_SPP).astype(np.float32),
+                            spp=IMAGE_SPP, sky=sky, bounces=st.bounces, nee_samples=st.nee_samples)
+
+
 if __name__ == "__main__":
     pcg()
     closest()
+    functions()
+    images()
     print("golden vectors written to", HERE)
