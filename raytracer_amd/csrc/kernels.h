@@ -366,153 +366,171 @@ __device__ __forceinline__ void order2(float& ta, int& ra, float& tb, int& rb) {
   }
 }
 
-// Closest mesh hit.  "while-while" traversal: all lanes of the wave first walk inner
-// nodes until each holds a leaf (or is done), then all test triangles; the two phases
-// do not mix within an iteration, which keeps more lanes busy in each.
+// Traversal state of one ray.  `cur` is the node (>= 0) or leaf (< 0, ~leaf word)
+// the lane stands on, kTraversalDone when the walk is over; `sp` its stack depth.
+struct Walk {
+  f3 o, d, inv;
+  int cur, sp;
+};
 template <int MODE>
-__device__ __forceinline__ void mesh_closest(const SceneDev& sc, const Geom& g, f3 o, f3 d, const Stack& stk,
-                                             float& best_t, uint32_t& best_slot) {
-  best_t = INFINITY;
-  best_slot = kMiss;
-  if (sc.num_nodes == 0) return;
-  uint32_t best_prim = kMiss;
-  const float eps = sc.eps;
-  int cur = 0;
-  int sp = 0;
+__device__ __forceinline__ void walk_begin(const SceneDev& sc, f3 o, f3 d, Walk& w) {
+  w.o = o;
+  w.d = d;
+  w.inv = MODE == kGlobalBvh4 ? safe_inverse(d) : mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  w.cur = sc.num_nodes == 0 ? (int)kTraversalDone : 0;
+  w.sp = 0;
+}
+struct ClosestHit {
+  float t;
+  uint32_t prim, slot;
+};
+
+// "while-while" traversal: all lanes of the wave first walk inner nodes until each
+// holds a leaf (or is done), then all test triangles; the two phases do not mix
+// within an iteration, which keeps more lanes busy in each.
+
+// Inner nodes of a closest-hit walk: front to back, until the lane reaches a leaf.
+template <int MODE>
+__device__ __forceinline__ void closest_nodes(const Geom& g, const Stack& stk, Walk& w, const ClosestHit& best) {
   if (MODE == kGlobalBvh4) {
-    const f3 inv = safe_inverse(d);
-    while (cur != kTraversalDone) {
-      while (cur >= 0) {
-        int4 refs;
-        Node4Test nt = test_node4(g.nodes + 4 * (size_t)cur, o, inv, best_t, refs);
-        float t0 = nt.hit[0] ? nt.tn[0] : INFINITY, t1 = nt.hit[1] ? nt.tn[1] : INFINITY;
-        float t2 = nt.hit[2] ? nt.tn[2] : INFINITY, t3 = nt.hit[3] ? nt.tn[3] : INFINITY;
-        int r0 = refs.x, r1 = refs.y, r2 = refs.z, r3 = refs.w;
-        // sort the four by entry distance (misses at +inf sink to the end)
-        order2(t0, r0, t1, r1);
-        order2(t2, r2, t3, r3);
-        order2(t0, r0, t2, r2);
-        order2(t1, r1, t3, r3);
-        order2(t1, r1, t2, r2);
-        if (t0 < INFINITY) {
-          if (t3 < INFINITY) stk.push(sp, r3);
-          if (t2 < INFINITY) stk.push(sp, r2);
-          if (t1 < INFINITY) stk.push(sp, r1);
-          cur = r0;
-        } else {
-          cur = sp == 0 ? kTraversalDone : stk.pop(sp);
-        }
-      }
-      while (cur < 0 && cur != kTraversalDone) {
-        leaf_closest(g, ~(uint32_t)cur, o, d, eps, best_t, best_prim, best_slot);
-        cur = sp == 0 ? kTraversalDone : stk.pop(sp);
+    while (w.cur >= 0) {
+      int4 refs;
+      Node4Test nt = test_node4(g.nodes + 4 * (size_t)w.cur, w.o, w.inv, best.t, refs);
+      float t0 = nt.hit[0] ? nt.tn[0] : INFINITY, t1 = nt.hit[1] ? nt.tn[1] : INFINITY;
+      float t2 = nt.hit[2] ? nt.tn[2] : INFINITY, t3 = nt.hit[3] ? nt.tn[3] : INFINITY;
+      int r0 = refs.x, r1 = refs.y, r2 = refs.z, r3 = refs.w;
+      // sort the four by entry distance (misses at +inf sink to the end)
+      order2(t0, r0, t1, r1);
+      order2(t2, r2, t3, r3);
+      order2(t0, r0, t2, r2);
+      order2(t1, r1, t3, r3);
+      order2(t1, r1, t2, r2);
+      if (t0 < INFINITY) {
+        if (t3 < INFINITY) stk.push(w.sp, r3);
+        if (t2 < INFINITY) stk.push(w.sp, r2);
+        if (t1 < INFINITY) stk.push(w.sp, r1);
+        w.cur = r0;
+      } else {
+        w.cur = w.sp == 0 ? kTraversalDone : stk.pop(w.sp);
       }
     }
   } else {
-    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    while (cur != kTraversalDone) {
-      while (cur >= 0) {
-        const float4* nd = g.nodes + 4 * (size_t)cur;
-        float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-        float tn0, tn1;
-        bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, o, inv, best_t, tn0);
-        bool h1 = slab(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, o, inv, best_t, tn1);
-        int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-        if (h0 && h1) {
-          bool swap = tn1 < tn0;
-          stk.push(sp, swap ? c0 : c1);
-          cur = swap ? c1 : c0;
-        } else if (h0) {
-          cur = c0;
-        } else if (h1) {
-          cur = c1;
-        } else {
-          cur = sp == 0 ? kTraversalDone : stk.pop(sp);
-        }
-      }
-      while (cur < 0 && cur != kTraversalDone) {
-        leaf_closest(g, ~(uint32_t)cur, o, d, eps, best_t, best_prim, best_slot);
-        cur = sp == 0 ? kTraversalDone : stk.pop(sp);
+    while (w.cur >= 0) {
+      const float4* nd = g.nodes + 4 * (size_t)w.cur;
+      float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+      float tn0, tn1;
+      bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, w.o, w.inv, best.t, tn0);
+      bool h1 = slab(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, w.o, w.inv, best.t, tn1);
+      int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+      if (h0 && h1) {
+        bool swap = tn1 < tn0;
+        stk.push(w.sp, swap ? c0 : c1);
+        w.cur = swap ? c1 : c0;
+      } else if (h0) {
+        w.cur = c0;
+      } else if (h1) {
+        w.cur = c1;
+      } else {
+        w.cur = w.sp == 0 ? kTraversalDone : stk.pop(w.sp);
       }
     }
   }
+}
+// Leaves of a closest-hit walk: until the lane pops an inner node or runs out.
+__device__ __forceinline__ void closest_leaves(const Geom& g, const Stack& stk, float eps, Walk& w,
+                                               ClosestHit& best) {
+  while (w.cur < 0 && w.cur != kTraversalDone) {
+    leaf_closest(g, ~(uint32_t)w.cur, w.o, w.d, eps, best.t, best.prim, best.slot);
+    w.cur = w.sp == 0 ? kTraversalDone : stk.pop(w.sp);
+  }
+}
+
+// Inner nodes of an any-hit walk (no ordering: every child the segment touches is visited).
+template <int MODE>
+__device__ __forceinline__ void any_nodes(const Geom& g, const Stack& stk, Walk& w, float tfar) {
+  if (MODE == kGlobalBvh4) {
+    while (w.cur >= 0) {
+      int4 refs;
+      Node4Test nt = test_node4(g.nodes + 4 * (size_t)w.cur, w.o, w.inv, tfar, refs);
+      int next = kTraversalDone;
+      if (nt.hit[3]) next = refs.w;
+      if (nt.hit[2]) {
+        if (next != kTraversalDone) stk.push(w.sp, next);
+        next = refs.z;
+      }
+      if (nt.hit[1]) {
+        if (next != kTraversalDone) stk.push(w.sp, next);
+        next = refs.y;
+      }
+      if (nt.hit[0]) {
+        if (next != kTraversalDone) stk.push(w.sp, next);
+        next = refs.x;
+      }
+      w.cur = next != kTraversalDone ? next : (w.sp == 0 ? kTraversalDone : stk.pop(w.sp));
+    }
+  } else {
+    while (w.cur >= 0) {
+      const float4* nd = g.nodes + 4 * (size_t)w.cur;
+      float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+      float tn0, tn1;
+      bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, w.o, w.inv, tfar, tn0);
+      bool h1 = slab(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, w.o, w.inv, tfar, tn1);
+      int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+      if (h0 && h1) {
+        stk.push(w.sp, c1);
+        w.cur = c0;
+      } else if (h0) {
+        w.cur = c0;
+      } else if (h1) {
+        w.cur = c1;
+      } else {
+        w.cur = w.sp == 0 ? kTraversalDone : stk.pop(w.sp);
+      }
+    }
+  }
+}
+// Leaves of an any-hit walk; the first hit ends the walk.
+__device__ __forceinline__ void any_leaves(const Geom& g, const Stack& stk, float eps, float tfar, Walk& w,
+                                           bool& hit) {
+  while (w.cur < 0 && w.cur != kTraversalDone) {
+    hit = hit || leaf_any(g, ~(uint32_t)w.cur, w.o, w.d, eps, tfar);
+    w.cur = (hit || w.sp == 0) ? kTraversalDone : stk.pop(w.sp);
+  }
+}
+
+// Closest mesh hit of one ray per lane.
+template <int MODE>
+__device__ __forceinline__ void mesh_closest(const SceneDev& sc, const Geom& g, f3 o, f3 d, const Stack& stk,
+                                             float& best_t, uint32_t& best_slot) {
+  ClosestHit best = {INFINITY, kMiss, kMiss};
+  Walk w;
+  walk_begin<MODE>(sc, o, d, w);
+  while (w.cur != kTraversalDone) {
+    closest_nodes<MODE>(g, stk, w, best);
+    closest_leaves(g, stk, sc.eps, w, best);
+  }
+  best_t = best.t;
+  best_slot = best.slot;
 }
 
 // Any mesh hit with eps < t < tfar.
 template <int MODE>
 __device__ __forceinline__ bool mesh_any(const SceneDev& sc, const Geom& g, f3 o, f3 d, float tfar,
                                          const Stack& stk) {
-  if (sc.num_nodes == 0) return false;
-  const float eps = sc.eps;
-  int cur = 0;
-  int sp = 0;
+  Walk w;
+  walk_begin<MODE>(sc, o, d, w);
   bool hit = false;
-  if (MODE == kGlobalBvh4) {
-    const f3 inv = safe_inverse(d);
-    while (cur != kTraversalDone) {
-      while (cur >= 0) {
-        int4 refs;
-        Node4Test nt = test_node4(g.nodes + 4 * (size_t)cur, o, inv, tfar, refs);
-        int next = kTraversalDone;
-        if (nt.hit[3]) next = refs.w;
-        if (nt.hit[2]) {
-          if (next != kTraversalDone) stk.push(sp, next);
-          next = refs.z;
-        }
-        if (nt.hit[1]) {
-          if (next != kTraversalDone) stk.push(sp, next);
-          next = refs.y;
-        }
-        if (nt.hit[0]) {
-          if (next != kTraversalDone) stk.push(sp, next);
-          next = refs.x;
-        }
-        cur = next != kTraversalDone ? next : (sp == 0 ? kTraversalDone : stk.pop(sp));
-      }
-      while (cur < 0 && cur != kTraversalDone) {
-        hit = hit || leaf_any(g, ~(uint32_t)cur, o, d, eps, tfar);
-        cur = (hit || sp == 0) ? kTraversalDone : stk.pop(sp);
-      }
-    }
-  } else {
-    const f3 inv = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-    while (cur != kTraversalDone) {
-      while (cur >= 0) {
-        const float4* nd = g.nodes + 4 * (size_t)cur;
-        float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-        float tn0, tn1;
-        bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, o, inv, tfar, tn0);
-        bool h1 = slab(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, o, inv, tfar, tn1);
-        int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-        if (h0 && h1) {
-          stk.push(sp, c1);
-          cur = c0;
-        } else if (h0) {
-          cur = c0;
-        } else if (h1) {
-          cur = c1;
-        } else {
-          cur = sp == 0 ? kTraversalDone : stk.pop(sp);
-        }
-      }
-      while (cur < 0 && cur != kTraversalDone) {
-        hit = hit || leaf_any(g, ~(uint32_t)cur, o, d, eps, tfar);
-        cur = (hit || sp == 0) ? kTraversalDone : stk.pop(sp);
-      }
-    }
+  while (w.cur != kTraversalDone) {
+    any_nodes<MODE>(g, stk, w, tfar);
+    any_leaves(g, stk, sc.eps, tfar, w, hit);
   }
   return hit;
 }
 
-// Scene::castRay, reference Scene.h:144-189: mesh first, then the spheres in
-// order (the first of equal t wins); the sphere wins only when strictly closer
-// than the mesh hit.  Returns t and an id: kMiss, kSphereBit|index, or triangle slot.
-template <int MODE>
-__device__ __forceinline__ void cast_ray(const SceneDev& sc, const Geom& g, f3 o, f3 d, const Stack& stk,
-                                         float& t_out, uint32_t& id_out) {
-  float tfar;
-  uint32_t slot;
-  mesh_closest<MODE>(sc, g, o, d, stk, tfar, slot);
+// The analytic objects of Scene::castRay (reference Scene.h:164-188): spheres in
+// order, then boxes and planes continuing the same list (t > EPS, the first of
+// equal t wins); the winner replaces the mesh hit only when strictly closer.
+__device__ __forceinline__ void analytic_closest(const SceneDev& sc, f3 o, f3 d, float& t_io, uint32_t& id_io) {
   float ts = INFINITY;
   uint32_t si = 0;
   for (uint32_t i = 0; i < sc.num_spheres; i++) {
@@ -523,7 +541,6 @@ __device__ __forceinline__ void cast_ray(const SceneDev& sc, const Geom& g, f3 o
       si = i;
     }
   }
-  // Boxes and planes continue the same list (same rule: t > EPS, first of equal t wins).
   for (uint32_t i = 0; i < sc.num_boxes; i++) {
     float4 a = sc.box0[i], b = sc.box1[i];
     float t = box_intersect(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), o, d, sc.eps);
@@ -540,20 +557,13 @@ __device__ __forceinline__ void cast_ray(const SceneDev& sc, const Geom& g, f3 o
       si = sc.num_spheres + sc.num_boxes + i;
     }
   }
-  if (ts < tfar) {
-    t_out = ts;
-    id_out = kSphereBit | si;
-    return;
+  if (ts < t_io) {
+    t_io = ts;
+    id_io = kSphereBit | si;
   }
-  t_out = tfar;
-  id_out = slot;  // kMiss when nothing was hit (tfar = inf)
 }
-
-// Scene::isOccluded, reference Scene.h:191-225, for a segment whose far end
-// tfar = distance - eps has been computed by the caller (distance >= 2 eps).
-template <int MODE>
-__device__ __forceinline__ bool occluded(const SceneDev& sc, const Geom& g, f3 o, f3 d, float tfar,
-                                         const Stack& stk) {
+// The analytic objects of Scene::isOccluded (reference Scene.h:196-202).
+__device__ __forceinline__ bool analytic_any(const SceneDev& sc, f3 o, f3 d, float tfar) {
   for (uint32_t i = 0; i < sc.num_spheres; i++) {
     float4 s = sc.sph0[i];
     float t = sphere_intersect(mk3(s.x, s.y, s.z), s.w, o, d, sc.eps);
@@ -569,6 +579,25 @@ __device__ __forceinline__ bool occluded(const SceneDev& sc, const Geom& g, f3 o
     float t = plane_intersect(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), o, d);
     if (t > sc.eps && t < tfar) return true;
   }
+  return false;
+}
+
+// Scene::castRay, reference Scene.h:144-189: mesh first, then the spheres in
+// order (the first of equal t wins); the sphere wins only when strictly closer
+// than the mesh hit.  Returns t and an id: kMiss, kSphereBit|index, or triangle slot.
+template <int MODE>
+__device__ __forceinline__ void cast_ray(const SceneDev& sc, const Geom& g, f3 o, f3 d, const Stack& stk,
+                                         float& t_out, uint32_t& id_out) {
+  mesh_closest<MODE>(sc, g, o, d, stk, t_out, id_out);  // id: triangle slot, kMiss when t = inf
+  analytic_closest(sc, o, d, t_out, id_out);
+}
+
+// Scene::isOccluded, reference Scene.h:191-225, for a segment whose far end
+// tfar = distance - eps has been computed by the caller (distance >= 2 eps).
+template <int MODE>
+__device__ __forceinline__ bool occluded(const SceneDev& sc, const Geom& g, f3 o, f3 d, float tfar,
+                                         const Stack& stk) {
+  if (analytic_any(sc, o, d, tfar)) return true;
   return mesh_any<MODE>(sc, g, o, d, tfar, stk);
 }
 
