@@ -53,6 +53,7 @@ struct SceneDev {
   const float4* tri0;    // per triangle slot: (a.xyz, primitive id bits)
   const float4* tri1;    //                    (b-a, material index bits)
   const float4* tri2;    //                    (c-a, 0)
+  const float4* tri3;    //                    ((b-a)x(c-a), 0)
   const float4* mat0;    // per material: (albedo.rgb, emission)
   const int* mat1;       //               surface
   // Analytic objects, in the order spheres, boxes, planes; object i of that
@@ -140,6 +141,7 @@ struct Geom {
   const float4* tri0;
   const float4* tri1;
   const float4* tri2;
+  const float4* tri3;  // (b-a)x(c-a), read by the LDS mode only
 };
 
 // How a traversal kernel reads the tree.
@@ -176,9 +178,10 @@ __device__ __forceinline__ Geom global_geom(const SceneDev& sc) {
   g.tri0 = sc.tri0;
   g.tri1 = sc.tri1;
   g.tri2 = sc.tri2;
+  g.tri3 = sc.tri3;
   return g;
 }
-// Copies [nodes | tri0 | tri1 | tri2] into `dst` (LDS) with the whole block and
+// Copies [nodes | tri0 | tri1 | tri2 | tri3] into `dst` (LDS) with the whole block and
 // returns the view; ends with a barrier, so every thread of the block must call it.
 __device__ __forceinline__ Geom stage_geom_lds(const SceneDev& sc, float4* dst, int tid, int nthreads) {
   const uint32_t nn = 4 * sc.num_nodes, nt = sc.num_tris;
@@ -187,6 +190,7 @@ __device__ __forceinline__ Geom stage_geom_lds(const SceneDev& sc, float4* dst, 
     dst[nn + k] = sc.tri0[k];
     dst[nn + nt + k] = sc.tri1[k];
     dst[nn + 2 * nt + k] = sc.tri2[k];
+    dst[nn + 3 * nt + k] = sc.tri3[k];
   }
   __syncthreads();
   Geom g;
@@ -194,6 +198,7 @@ __device__ __forceinline__ Geom stage_geom_lds(const SceneDev& sc, float4* dst, 
   g.tri0 = dst + nn;
   g.tri1 = dst + nn + nt;
   g.tri2 = dst + nn + 2 * nt;
+  g.tri3 = dst + nn + 3 * nt;
   return g;
 }
 
@@ -203,15 +208,31 @@ __device__ __forceinline__ Geom stage_geom_lds(const SceneDev& sc, float4* dst, 
 // Triangle::intersect, reference Obj.h:110-121, on a triangle stored as
 // (a, b-a, c-a).  The comparisons keep the reference's form so that infinities
 // and NaNs from a ray parallel to the plane fall through identically.
-__device__ __forceinline__ float tri_intersect(f3 a, f3 ba, f3 ca, f3 o, f3 d) {
+__device__ __forceinline__ float tri_intersect_n(f3 a, f3 ba, f3 ca, f3 n, f3 o, f3 d) {
   f3 roa = vsub(o, a);
-  f3 n = vcross(ba, ca);
   f3 q = vcross(roa, d);
   float inv = 1.0f / vdot(d, n);
   float u = inv * -vdot(q, ca);
   float v = inv * vdot(q, ba);
   if (u < 0.0f || u > 1.0f || v < 0.0f || (u + v) > 1.0f) return INFINITY;
   return inv * -vdot(n, roa);
+}
+__device__ __forceinline__ float tri_intersect(f3 a, f3 ba, f3 ca, f3 o, f3 d) {
+  return tri_intersect_n(a, ba, ca, vcross(ba, ca), o, d);
+}
+// Triangle `slot` against a ray.  The LDS copy of a small scene carries the normal
+// (b-a)x(c-a), computed on the host with the same float operations, so the lanes
+// do not recompute it; elsewhere the fourth fetch would cost more than the nine
+// operations it saves.
+template <int MODE>
+__device__ __forceinline__ float tri_test(const Geom& g, uint32_t slot, f3 o, f3 d, uint32_t& prim) {
+  float4 A = g.tri0[slot], B = g.tri1[slot], C = g.tri2[slot];
+  prim = __float_as_uint(A.w);
+  if (MODE == kLdsBvh2) {
+    float4 N = g.tri3[slot];
+    return tri_intersect_n(mk3(A.x, A.y, A.z), mk3(B.x, B.y, B.z), mk3(C.x, C.y, C.z), mk3(N.x, N.y, N.z), o, d);
+  }
+  return tri_intersect(mk3(A.x, A.y, A.z), mk3(B.x, B.y, B.z), mk3(C.x, C.y, C.z), o, d);
 }
 
 // Sphere::intersect, reference Obj.h:257-268.
@@ -263,32 +284,34 @@ __device__ __forceinline__ float plane_intersect(f3 pt, f3 n, f3 o, f3 d) {
   return vdot(vsub(pt, o), n) / vdot(d, n);
 }
 
-// Slab test of one child box against [0, tmax].  fminf/fmaxf drop a NaN operand
-// (0*inf when the origin lies on a slab plane of an axis-parallel ray), which
-// leaves that slab unconstrained: conservative.  The far end is widened by two
-// ulps so rounding never culls a box the ray touches.
+// Slab test of one child box against [0, tmax] in the form t = plane*inv + add,
+// one fma per plane.  `add` is -(o*inv), whose rounding error acts like a shift of
+// the plane by up to |o| 2^-24; walk_begin moves the two addends of an axis apart
+// by four times that, towards "box larger", so the test stays conservative for any
+// origin.  The comparison's slack covers the relative errors (fma rounding and the
+// reciprocal's ulp).  The inverse is finite (clamped), so no term is NaN.
 __device__ __forceinline__ bool slab(float lox, float hix, float loy, float hiy, float loz, float hiz,
-                                     f3 o, f3 inv, float tmax, float& tnear) {
-  float ax = (lox - o.x) * inv.x, bx = (hix - o.x) * inv.x;
-  float ay = (loy - o.y) * inv.y, by = (hiy - o.y) * inv.y;
-  float az = (loz - o.z) * inv.z, bz = (hiz - o.z) * inv.z;
+                                     f3 inv, f3 add_lo, f3 add_hi, float tmax, float& tnear) {
+  float ax = __builtin_fmaf(lox, inv.x, add_lo.x), bx = __builtin_fmaf(hix, inv.x, add_hi.x);
+  float ay = __builtin_fmaf(loy, inv.y, add_lo.y), by = __builtin_fmaf(hiy, inv.y, add_hi.y);
+  float az = __builtin_fmaf(loz, inv.z, add_lo.z), bz = __builtin_fmaf(hiz, inv.z, add_hi.z);
   float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
   float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
   tnear = tn;
-  return tn <= tf * 1.0000004f;
+  return tn <= tf * 1.000001f;
 }
 
 // One triangle of a leaf against the running closest hit, with the rules of
 // Mesh::intersect (reference Obj.h:184-195): a hit needs eps < t; the smallest t
 // wins and, among equal t, the lowest primitive id (the linear scan keeps the first).
+template <int MODE>
 __device__ __forceinline__ void leaf_closest(const Geom& g, uint32_t leaf, f3 o, f3 d, float eps,
                                              float& best_t, uint32_t& best_prim, uint32_t& best_slot) {
   uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
   for (uint32_t k = 0; k < cnt; k++) {
     uint32_t slot = first + k;
-    float4 A = g.tri0[slot], B = g.tri1[slot], C = g.tri2[slot];
-    float t = tri_intersect(mk3(A.x, A.y, A.z), mk3(B.x, B.y, B.z), mk3(C.x, C.y, C.z), o, d);
-    uint32_t prim = __float_as_uint(A.w);
+    uint32_t prim;
+    float t = tri_test<MODE>(g, slot, o, d, prim);
     if (eps < t && t < INFINITY && (t < best_t || (t == best_t && prim < best_prim))) {
       best_t = t;
       best_prim = prim;
@@ -298,13 +321,14 @@ __device__ __forceinline__ void leaf_closest(const Geom& g, uint32_t leaf, f3 o,
 }
 // Any triangle of a leaf with eps < t < tfar (the interval Scene::isOccluded gives
 // Embree, reference Scene.h:216-217, ends taken open as in Mesh::intersect).
+template <int MODE>
 __device__ __forceinline__ bool leaf_any(const Geom& g, uint32_t leaf, f3 o, f3 d, float eps, float tfar) {
   uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
   bool hit = false;
   for (uint32_t k = 0; k < cnt; k++) {
     uint32_t slot = first + k;
-    float4 A = g.tri0[slot], B = g.tri1[slot], C = g.tri2[slot];
-    float t = tri_intersect(mk3(A.x, A.y, A.z), mk3(B.x, B.y, B.z), mk3(C.x, C.y, C.z), o, d);
+    uint32_t prim;
+    float t = tri_test<MODE>(g, slot, o, d, prim);
     if (eps < t && t < tfar) hit = true;
   }
   return hit;
@@ -355,6 +379,15 @@ __device__ __forceinline__ f3 safe_inverse(f3 d) {
   float z = fabsf(d.z) < tiny ? copysignf(tiny, d.z) : d.z;
   return mk3(1.0f / x, 1.0f / y, 1.0f / z);
 }
+// The same with the hardware reciprocal (one ulp): only for box tests whose
+// comparison allows for it.
+__device__ __forceinline__ f3 fast_safe_inverse(f3 d) {
+  const float tiny = 1.0e-20f;
+  float x = fabsf(d.x) < tiny ? copysignf(tiny, d.x) : d.x;
+  float y = fabsf(d.y) < tiny ? copysignf(tiny, d.y) : d.y;
+  float z = fabsf(d.z) < tiny ? copysignf(tiny, d.z) : d.z;
+  return mk3(__builtin_amdgcn_rcpf(x), __builtin_amdgcn_rcpf(y), __builtin_amdgcn_rcpf(z));
+}
 __device__ __forceinline__ void order2(float& ta, int& ra, float& tb, int& rb) {
   if (tb < ta) {
     float t = ta;
@@ -370,13 +403,24 @@ __device__ __forceinline__ void order2(float& ta, int& ra, float& tb, int& rb) {
 // the lane stands on, kTraversalDone when the walk is over; `sp` its stack depth.
 struct Walk {
   f3 o, d, inv;
+  f3 add_lo, add_hi;  // two-child nodes only: the slab test's addends, see slab()
   int cur, sp;
 };
 template <int MODE>
 __device__ __forceinline__ void walk_begin(const SceneDev& sc, f3 o, f3 d, Walk& w) {
   w.o = o;
   w.d = d;
-  w.inv = MODE == kGlobalBvh4 ? safe_inverse(d) : mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  if (MODE == kGlobalBvh4) {
+    w.inv = safe_inverse(d);
+  } else {
+    w.inv = fast_safe_inverse(d);
+    const f3 nb = mk3(-(o.x * w.inv.x), -(o.y * w.inv.y), -(o.z * w.inv.z));
+    const float k = 2.3841858e-7f;  // 2^-22
+    const f3 e = mk3(copysignf(fabsf(nb.x) * k, w.inv.x), copysignf(fabsf(nb.y) * k, w.inv.y),
+                     copysignf(fabsf(nb.z) * k, w.inv.z));
+    w.add_lo = mk3(nb.x - e.x, nb.y - e.y, nb.z - e.z);
+    w.add_hi = mk3(nb.x + e.x, nb.y + e.y, nb.z + e.z);
+  }
   w.cur = sc.num_nodes == 0 ? (int)kTraversalDone : 0;
   w.sp = 0;
 }
@@ -419,8 +463,8 @@ __device__ __forceinline__ void closest_nodes(const Geom& g, const Stack& stk, W
       const float4* nd = g.nodes + 4 * (size_t)w.cur;
       float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
       float tn0, tn1;
-      bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, w.o, w.inv, best.t, tn0);
-      bool h1 = slab(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, w.o, w.inv, best.t, tn1);
+      bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, w.inv, w.add_lo, w.add_hi, best.t, tn0);
+      bool h1 = slab(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, w.inv, w.add_lo, w.add_hi, best.t, tn1);
       int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
       if (h0 && h1) {
         bool swap = tn1 < tn0;
@@ -437,10 +481,11 @@ __device__ __forceinline__ void closest_nodes(const Geom& g, const Stack& stk, W
   }
 }
 // Leaves of a closest-hit walk: until the lane pops an inner node or runs out.
+template <int MODE>
 __device__ __forceinline__ void closest_leaves(const Geom& g, const Stack& stk, float eps, Walk& w,
                                                ClosestHit& best) {
   while (w.cur < 0 && w.cur != kTraversalDone) {
-    leaf_closest(g, ~(uint32_t)w.cur, w.o, w.d, eps, best.t, best.prim, best.slot);
+    leaf_closest<MODE>(g, ~(uint32_t)w.cur, w.o, w.d, eps, best.t, best.prim, best.slot);
     w.cur = w.sp == 0 ? kTraversalDone : stk.pop(w.sp);
   }
 }
@@ -473,8 +518,8 @@ __device__ __forceinline__ void any_nodes(const Geom& g, const Stack& stk, Walk&
       const float4* nd = g.nodes + 4 * (size_t)w.cur;
       float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
       float tn0, tn1;
-      bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, w.o, w.inv, tfar, tn0);
-      bool h1 = slab(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, w.o, w.inv, tfar, tn1);
+      bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, w.inv, w.add_lo, w.add_hi, tfar, tn0);
+      bool h1 = slab(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, w.inv, w.add_lo, w.add_hi, tfar, tn1);
       int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
       if (h0 && h1) {
         stk.push(w.sp, c1);
@@ -490,10 +535,11 @@ __device__ __forceinline__ void any_nodes(const Geom& g, const Stack& stk, Walk&
   }
 }
 // Leaves of an any-hit walk; the first hit ends the walk.
+template <int MODE>
 __device__ __forceinline__ void any_leaves(const Geom& g, const Stack& stk, float eps, float tfar, Walk& w,
                                            bool& hit) {
   while (w.cur < 0 && w.cur != kTraversalDone) {
-    hit = hit || leaf_any(g, ~(uint32_t)w.cur, w.o, w.d, eps, tfar);
+    hit = hit || leaf_any<MODE>(g, ~(uint32_t)w.cur, w.o, w.d, eps, tfar);
     w.cur = (hit || w.sp == 0) ? kTraversalDone : stk.pop(w.sp);
   }
 }
@@ -507,7 +553,7 @@ __device__ __forceinline__ void mesh_closest(const SceneDev& sc, const Geom& g, 
   walk_begin<MODE>(sc, o, d, w);
   while (w.cur != kTraversalDone) {
     closest_nodes<MODE>(g, stk, w, best);
-    closest_leaves(g, stk, sc.eps, w, best);
+    closest_leaves<MODE>(g, stk, sc.eps, w, best);
   }
   best_t = best.t;
   best_slot = best.slot;
@@ -522,7 +568,7 @@ __device__ __forceinline__ bool mesh_any(const SceneDev& sc, const Geom& g, f3 o
   bool hit = false;
   while (w.cur != kTraversalDone) {
     any_nodes<MODE>(g, stk, w, tfar);
-    any_leaves(g, stk, sc.eps, tfar, w, hit);
+    any_leaves<MODE>(g, stk, sc.eps, tfar, w, hit);
   }
   return hit;
 }

@@ -90,7 +90,7 @@ struct rtx_ctx {
 
   // scene
   bool have_scene = false;
-  DevBuf<float4> nodes, tri0, tri1, tri2, mat0, sph0, sph1, box0, box1, pln0, pln1, light0, light1, light2, light3;
+  DevBuf<float4> nodes, tri0, tri1, tri2, tri3, mat0, sph0, sph1, box0, box1, pln0, pln1, light0, light1, light2, light3;
   DevBuf<int> mat1, sph2;
   rtx::SceneDev scene{};
   rtx_scene_info info{};
@@ -155,7 +155,7 @@ struct DeviceGuard {
 void free_ctx(rtx_ctx* c) {
   if (!c) return;
   DeviceGuard g(c->device);
-  c->nodes.release(); c->tri0.release(); c->tri1.release(); c->tri2.release();
+  c->nodes.release(); c->tri0.release(); c->tri1.release(); c->tri2.release(); c->tri3.release();
   c->mat0.release(); c->mat1.release(); c->sph0.release(); c->sph1.release(); c->sph2.release();
   c->box0.release(); c->box1.release(); c->pln0.release(); c->pln1.release();
   c->light0.release(); c->light1.release(); c->light2.release(); c->light3.release();
@@ -291,7 +291,7 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
   // Larger scenes stream their nodes from L2/HBM: four-child quantised nodes (two levels per
   // 64-byte fetch).  Leaves hold at most 2 triangles in both forms (a box test costs about a
   // third of a triangle test; measured best on the 1M-triangle mesh as well).
-  const bool small_scene = s->num_triangles > 0 && s->num_triangles * (48 + 32 + 8) <= kLdsSceneMaxBytes;
+  const bool small_scene = s->num_triangles > 0 && s->num_triangles * (64 + 32 + 8) <= kLdsSceneMaxBytes;
   rtx::FlatBvh bvh;
   rtx::build_bvh(s->triangles, s->num_triangles, 2u, small_scene ? 2u : 4u, bvh);
   // Stack: two-child trees keep all of it in LDS; the wide tree keeps kWideLdsStack entries
@@ -307,7 +307,7 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
   }
 
   const size_t nt = s->num_triangles;
-  std::vector<float4> nodes(bvh.nodes.size() / 4), t0(nt), t1(nt), t2(nt);
+  std::vector<float4> nodes(bvh.nodes.size() / 4), t0(nt), t1(nt), t2(nt), t3(nt);
   std::memcpy(nodes.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(float));
   for (size_t slot = 0; slot < nt; slot++) {
     uint32_t prim = bvh.order[slot];
@@ -323,6 +323,8 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
     t0[slot] = make_float4(p[0], p[1], p[2], fprim);
     t1[slot] = make_float4(bax, bay, baz, fmi);
     t2[slot] = make_float4(cax, cay, caz, 0.f);
+    // (b-a)x(c-a) with the operations of the device's cross product (no contraction on either side)
+    t3[slot] = make_float4(bay * caz - baz * cay, baz * cax - bax * caz, bax * cay - bay * cax, 0.f);
   }
   std::vector<float4> m0(s->num_materials);
   std::vector<int> m1(s->num_materials);
@@ -381,6 +383,7 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
   HIP_TRY(c->tri0.upload(t0));
   HIP_TRY(c->tri1.upload(t1));
   HIP_TRY(c->tri2.upload(t2));
+  HIP_TRY(c->tri3.upload(t3));
   HIP_TRY(c->mat0.upload(m0));
   HIP_TRY(c->mat1.upload(m1));
   HIP_TRY(c->sph0.upload(sp0));
@@ -396,7 +399,7 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
   HIP_TRY(c->light3.upload(l3));
 
   rtx::SceneDev& d = c->scene;
-  d.nodes = c->nodes.p; d.tri0 = c->tri0.p; d.tri1 = c->tri1.p; d.tri2 = c->tri2.p;
+  d.nodes = c->nodes.p; d.tri0 = c->tri0.p; d.tri1 = c->tri1.p; d.tri2 = c->tri2.p; d.tri3 = c->tri3.p;
   d.mat0 = c->mat0.p; d.mat1 = c->mat1.p;
   d.sph0 = c->sph0.p; d.sph1 = c->sph1.p; d.sph2 = c->sph2.p;
   d.box0 = c->box0.p; d.box1 = c->box1.p; d.pln0 = c->pln0.p; d.pln1 = c->pln1.p;
@@ -414,7 +417,7 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
   d.max_bounces = c->cfg.max_bounces;
   d.integrator = c->cfg.integrator;
   c->stack_entries = stack_entries;
-  c->lds_scene_bytes = (nodes.size() + 3 * nt) * sizeof(float4);
+  c->lds_scene_bytes = (nodes.size() + 4 * nt) * sizeof(float4);
   if (bvh.width == 4)
     c->trace_mode = rtx::kGlobalBvh4;
   else if (nt > 0 && c->lds_scene_bytes <= kLdsSceneMaxBytes)
