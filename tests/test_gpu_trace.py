@@ -128,6 +128,50 @@ def test_degenerate_rays(oracle, rtx_lib):
         assert_same_hits(r.trace_closest(rays), osc.trace_closest(rays, use_bvh=False))
 
 
+@pytest.mark.parametrize("name", ["soup_lds", "cornell", "soup10k"])
+def test_far_origins_and_axis_parallel_rays(name, oracle, rtx_lib):
+    """Box tests must never cull a hit of the float triangle test, whatever the origin: rays
+    aimed at the scene from 10 to 1e4 scene sizes away (the box test works on origin*inverse
+    products there) and axis-parallel rays through a grid of origins (zero direction
+    components).  soup_lds is small enough for the LDS-resident two-child tree.
+    (From about 1e6 scene sizes away the float triangle test itself returns t with errors
+    as large as the scene; a traversal that culls by the closest t so far then differs from
+    a linear scan whatever the boxes are.  That range is outside the guarantee.)"""
+    sc = {"soup_lds": lambda: scenes.soup(140, 2, seed=8), "cornell": scenes.cornell,
+          "soup10k": lambda: scenes.soup(10000, 3)}[name]()
+    cfg = Config(width=64, height=64, pool_paths=1 << 14)
+    osc = oracle.OracleScene(sc, cfg)
+    rng = np.random.default_rng(17)
+    tri = sc.triangles.reshape(-1, 3, 3)
+    lo, hi = tri.min((0, 1)), tri.max((0, 1))
+    rays = []
+    for dist in (10.0, 1e2, 1e3, 1e4):
+        target = rng.uniform(lo, hi, (3000, 3))
+        dirs = rng.normal(size=(3000, 3))
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        o = (target - dirs * dist).astype(np.float32)
+        d = target - o.astype(np.float64)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rays.append(np.concatenate([o, d.astype(np.float32)], 1))
+    for axis in range(3):
+        for sign in (1.0, -1.0):
+            g = rng.uniform(lo, hi, (1500, 3))
+            g[:, axis] = (lo[axis] - 5.0) if sign > 0 else (hi[axis] + 5.0)
+            d = np.zeros((1500, 3))
+            d[:, axis] = sign
+            rays.append(np.concatenate([g, d], 1))
+    rays = np.concatenate(rays).astype(np.float32)
+    with Renderer(cfg) as r:
+        info = r.set_scene(sc)
+        assert (info.bvh_width == 2) == (name != "soup10k")
+        want = osc.trace_closest(rays, use_bvh=False)
+        assert_same_hits(r.trace_closest(rays), want)
+        assert (want[0] != 0).sum() > 1000
+        dist = np.where(want[0] != 0, want[2] * 1.5, 10.0).astype(np.float32)
+        dist[~np.isfinite(dist)] = 10.0
+        assert np.array_equal(r.trace_occluded(rays, dist), osc.trace_occluded(rays, dist, use_bvh=False))
+
+
 @pytest.mark.parametrize("name,make", [("cornell", scenes.cornell), ("soup2k", lambda: scenes.soup(2000, 3, seed=4))])
 def test_matches_committed_vectors(name, make, rtx_lib):
     """The committed fixed ray sets (tests/golden/make_golden.py): bit-exact kind, id, t and occlusion."""
