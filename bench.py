@@ -50,6 +50,7 @@ def workloads():
         "sample3_mis_cornell": dict(scene=lambda: scenes.cornell(), sky=0, width=1024, height=1024, spp=256),
         "sample3_mis_cornell_4lights": dict(scene=lambda: scenes.cornell(lights=4), sky=0, width=1024, height=1024, spp=256),
         "mesh_1m": dict(scene=lambda: scenes.terrain(707), sky=0, width=1920, height=1080, spp=256),
+        "mis_4k": dict(scene=lambda: scenes.cornell(), sky=0, width=3840, height=2160, spp=4096),
     }
 
 
@@ -99,6 +100,9 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--pool", type=int, default=0, help="in-flight path pool (0 = library default)")
     ap.add_argument("--strong", action="store_true", help="split the workload's spp across ranks instead")
+    ap.add_argument("--tiles", type=int, default=1,
+                    help="row bands: ranks form TILES groups, group g renders band g of the frame and the "
+                         "ranks of a group take disjoint sample ranges (for frames too large per GPU)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -132,11 +136,15 @@ def main():
     W = args.width or wl["width"]
     H = args.height or wl["height"]
     spp_full = args.spp or wl["spp"]
+    if world % args.tiles:
+        raise SystemExit("--tiles must divide the number of ranks")
+    band, replica, replicas = rank % args.tiles, rank // args.tiles, world // args.tiles
+    row0, row1 = band * H // args.tiles, (band + 1) * H // args.tiles
     if args.strong:
-        spp = spp_full // world + (1 if rank < spp_full % world else 0)
-        base = rank * (spp_full // world) + min(rank, spp_full % world)
+        spp = spp_full // replicas + (1 if replica < spp_full % replicas else 0)
+        base = replica * (spp_full // replicas) + min(replica, spp_full % replicas)
     else:
-        spp, base = spp_full, rank * spp_full
+        spp, base = spp_full, replica * spp_full
     cfg = Config(width=W, height=H, sky=wl["sky"], device=local_rank, pool_paths=args.pool)
     sc = wl["scene"]()
 
@@ -147,8 +155,8 @@ def main():
 
     def step():
         accum.zero_()
-        r.render(accum, spp, sample_base=base, seed=0x5EED, stream=stream)
-        if world > 1:
+        r.render(accum, spp, sample_base=base, seed=0x5EED, row0=row0, row1=row1, stream=stream)
+        if world > 1:  # bands are disjoint and zero elsewhere: one sum serves tiles and sample ranges
             if args.backend == "nccl":
                 dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
             else:
@@ -191,7 +199,7 @@ def main():
         r.reset_stats()
         r.set_profiling(True)
         accum.zero_()
-        r.render(accum, spp, sample_base=base, seed=0x5EED, stream=stream)
+        r.render(accum, spp, sample_base=base, seed=0x5EED, row0=row0, row1=row1, stream=stream)
         torch.cuda.synchronize()
         r.set_profiling(False)
         p = r.stats()
@@ -231,7 +239,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload} {W}x{H} {spp_full} spp" +
-                                   (" per GPU (disjoint sample ranges, RCCL reduce)" if world > 1 and not args.strong else ""),
+                                   (" per GPU (disjoint sample ranges, RCCL reduce)" if world > 1 and not args.strong else "") +
+                                   (f", {args.tiles} row bands" if args.tiles > 1 else ""),
                        "triangles": int(info.num_triangles), "spheres": int(info.num_spheres),
                        "lights": int(info.num_lights), "bvh_nodes": int(info.num_nodes),
                        "pool_paths": int(args.pool) or (1 << 23)},
