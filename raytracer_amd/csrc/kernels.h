@@ -50,10 +50,8 @@ constexpr int kTraversalDone = (int)0x80000000u;
 
 struct SceneDev {
   const float4* nodes;   // 4 per BVH node (bvh_build.h)
-  const float4* tri0;    // per triangle slot: (a.xyz, primitive id bits)
-  const float4* tri1;    //                    (b-a, material index bits)
-  const float4* tri2;    //                    (c-a, 0)
-  const float4* tri3;    //                    ((b-a)x(c-a), 0)
+  const float4* tris;    // per triangle slot, one 64-byte record: (a.xyz, primitive id bits),
+                         // (b-a, material index bits), (c-a, 0), ((b-a)x(c-a), 0)
   const float4* mat0;    // per material: (albedo.rgb, emission)
   const int* mat1;       //               surface
   // Analytic objects, in the order spheres, boxes, planes; object i of that
@@ -138,10 +136,7 @@ struct RenderParams {
 // instead of an L1/L2 round trip, and stop competing for the L1's 64 B/clk).
 struct Geom {
   const float4* nodes;
-  const float4* tri0;
-  const float4* tri1;
-  const float4* tri2;
-  const float4* tri3;  // (b-a)x(c-a), read by the LDS mode only
+  const float4* tris;  // four float4 per triangle slot
 };
 
 // How a traversal kernel reads the tree.
@@ -175,30 +170,19 @@ struct Stack {
 __device__ __forceinline__ Geom global_geom(const SceneDev& sc) {
   Geom g;
   g.nodes = sc.nodes;
-  g.tri0 = sc.tri0;
-  g.tri1 = sc.tri1;
-  g.tri2 = sc.tri2;
-  g.tri3 = sc.tri3;
+  g.tris = sc.tris;
   return g;
 }
-// Copies [nodes | tri0 | tri1 | tri2 | tri3] into `dst` (LDS) with the whole block and
+// Copies [nodes | triangle records] into `dst` (LDS) with the whole block and
 // returns the view; ends with a barrier, so every thread of the block must call it.
 __device__ __forceinline__ Geom stage_geom_lds(const SceneDev& sc, float4* dst, int tid, int nthreads) {
-  const uint32_t nn = 4 * sc.num_nodes, nt = sc.num_tris;
+  const uint32_t nn = 4 * sc.num_nodes, nt = 4 * sc.num_tris;
   for (uint32_t k = tid; k < nn; k += nthreads) dst[k] = sc.nodes[k];
-  for (uint32_t k = tid; k < nt; k += nthreads) {
-    dst[nn + k] = sc.tri0[k];
-    dst[nn + nt + k] = sc.tri1[k];
-    dst[nn + 2 * nt + k] = sc.tri2[k];
-    dst[nn + 3 * nt + k] = sc.tri3[k];
-  }
+  for (uint32_t k = tid; k < nt; k += nthreads) dst[nn + k] = sc.tris[k];
   __syncthreads();
   Geom g;
   g.nodes = dst;
-  g.tri0 = dst + nn;
-  g.tri1 = dst + nn + nt;
-  g.tri2 = dst + nn + 2 * nt;
-  g.tri3 = dst + nn + 3 * nt;
+  g.tris = dst + nn;
   return g;
 }
 
@@ -220,19 +204,14 @@ __device__ __forceinline__ float tri_intersect_n(f3 a, f3 ba, f3 ca, f3 n, f3 o,
 __device__ __forceinline__ float tri_intersect(f3 a, f3 ba, f3 ca, f3 o, f3 d) {
   return tri_intersect_n(a, ba, ca, vcross(ba, ca), o, d);
 }
-// Triangle `slot` against a ray.  The LDS copy of a small scene carries the normal
-// (b-a)x(c-a), computed on the host with the same float operations, so the lanes
-// do not recompute it; elsewhere the fourth fetch would cost more than the nine
-// operations it saves.
-template <int MODE>
+// Triangle `slot` against a ray.  The record carries the normal (b-a)x(c-a),
+// computed on the host with the same float operations (no contraction on either
+// side), so the lanes do not recompute it; it shares the record's 64-byte line.
 __device__ __forceinline__ float tri_test(const Geom& g, uint32_t slot, f3 o, f3 d, uint32_t& prim) {
-  float4 A = g.tri0[slot], B = g.tri1[slot], C = g.tri2[slot];
+  const float4* r = g.tris + 4 * (size_t)slot;
+  float4 A = r[0], B = r[1], C = r[2], N = r[3];
   prim = __float_as_uint(A.w);
-  if (MODE == kLdsBvh2) {
-    float4 N = g.tri3[slot];
-    return tri_intersect_n(mk3(A.x, A.y, A.z), mk3(B.x, B.y, B.z), mk3(C.x, C.y, C.z), mk3(N.x, N.y, N.z), o, d);
-  }
-  return tri_intersect(mk3(A.x, A.y, A.z), mk3(B.x, B.y, B.z), mk3(C.x, C.y, C.z), o, d);
+  return tri_intersect_n(mk3(A.x, A.y, A.z), mk3(B.x, B.y, B.z), mk3(C.x, C.y, C.z), mk3(N.x, N.y, N.z), o, d);
 }
 
 // Sphere::intersect, reference Obj.h:257-268.
@@ -311,7 +290,7 @@ __device__ __forceinline__ void leaf_closest(const Geom& g, uint32_t leaf, f3 o,
   for (uint32_t k = 0; k < cnt; k++) {
     uint32_t slot = first + k;
     uint32_t prim;
-    float t = tri_test<MODE>(g, slot, o, d, prim);
+    float t = tri_test(g, slot, o, d, prim);
     if (eps < t && t < INFINITY && (t < best_t || (t == best_t && prim < best_prim))) {
       best_t = t;
       best_prim = prim;
@@ -328,7 +307,7 @@ __device__ __forceinline__ bool leaf_any(const Geom& g, uint32_t leaf, f3 o, f3 
   for (uint32_t k = 0; k < cnt; k++) {
     uint32_t slot = first + k;
     uint32_t prim;
-    float t = tri_test<MODE>(g, slot, o, d, prim);
+    float t = tri_test(g, slot, o, d, prim);
     if (eps < t && t < tfar) hit = true;
   }
   return hit;
@@ -670,8 +649,8 @@ __device__ __forceinline__ void hit_surface(const SceneDev& sc, const Geom& g, u
     emission = m.w;
     surface = sc.sph2[i];
   } else {
-    float4 B = g.tri1[id], C = g.tri2[id];
-    n = vnormalized(vcross(mk3(B.x, B.y, B.z), mk3(C.x, C.y, C.z)));
+    float4 B = g.tris[4 * (size_t)id + 1], N = g.tris[4 * (size_t)id + 3];
+    n = vnormalized(mk3(N.x, N.y, N.z));
     uint32_t mi = __float_as_uint(B.w);
     float4 m = sc.mat0[mi];
     albedo = mk3(m.x, m.y, m.z);
@@ -1324,7 +1303,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest(SceneDev sc, const floa
       prim[i] = k;
     } else {
       kind[i] = 1;
-      prim[i] = __float_as_uint(sc.tri0[id].w);
+      prim[i] = __float_as_uint(sc.tris[4 * (size_t)id].w);
     }
   }
   t_out[i] = t;

@@ -90,7 +90,7 @@ struct rtx_ctx {
 
   // scene
   bool have_scene = false;
-  DevBuf<float4> nodes, tri0, tri1, tri2, tri3, mat0, sph0, sph1, box0, box1, pln0, pln1, light0, light1, light2, light3;
+  DevBuf<float4> nodes, tris, mat0, sph0, sph1, box0, box1, pln0, pln1, light0, light1, light2, light3;
   DevBuf<int> mat1, sph2;
   rtx::SceneDev scene{};
   rtx_scene_info info{};
@@ -155,7 +155,7 @@ struct DeviceGuard {
 void free_ctx(rtx_ctx* c) {
   if (!c) return;
   DeviceGuard g(c->device);
-  c->nodes.release(); c->tri0.release(); c->tri1.release(); c->tri2.release(); c->tri3.release();
+  c->nodes.release(); c->tris.release();
   c->mat0.release(); c->mat1.release(); c->sph0.release(); c->sph1.release(); c->sph2.release();
   c->box0.release(); c->box1.release(); c->pln0.release(); c->pln1.release();
   c->light0.release(); c->light1.release(); c->light2.release(); c->light3.release();
@@ -307,7 +307,7 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
   }
 
   const size_t nt = s->num_triangles;
-  std::vector<float4> nodes(bvh.nodes.size() / 4), t0(nt), t1(nt), t2(nt), t3(nt);
+  std::vector<float4> nodes(bvh.nodes.size() / 4), tr(4 * nt);
   std::memcpy(nodes.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(float));
   for (size_t slot = 0; slot < nt; slot++) {
     uint32_t prim = bvh.order[slot];
@@ -320,11 +320,11 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
     float fprim, fmi;
     std::memcpy(&fprim, &prim, 4);
     std::memcpy(&fmi, &mi, 4);
-    t0[slot] = make_float4(p[0], p[1], p[2], fprim);
-    t1[slot] = make_float4(bax, bay, baz, fmi);
-    t2[slot] = make_float4(cax, cay, caz, 0.f);
+    tr[4 * slot] = make_float4(p[0], p[1], p[2], fprim);
+    tr[4 * slot + 1] = make_float4(bax, bay, baz, fmi);
+    tr[4 * slot + 2] = make_float4(cax, cay, caz, 0.f);
     // (b-a)x(c-a) with the operations of the device's cross product (no contraction on either side)
-    t3[slot] = make_float4(bay * caz - baz * cay, baz * cax - bax * caz, bax * cay - bay * cax, 0.f);
+    tr[4 * slot + 3] = make_float4(bay * caz - baz * cay, baz * cax - bax * caz, bax * cay - bay * cax, 0.f);
   }
   std::vector<float4> m0(s->num_materials);
   std::vector<int> m1(s->num_materials);
@@ -380,10 +380,7 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(c->spill.alloc(spill_entries * (size_t)c->pool));
   HIP_TRY(c->nodes.upload(nodes));
-  HIP_TRY(c->tri0.upload(t0));
-  HIP_TRY(c->tri1.upload(t1));
-  HIP_TRY(c->tri2.upload(t2));
-  HIP_TRY(c->tri3.upload(t3));
+  HIP_TRY(c->tris.upload(tr));
   HIP_TRY(c->mat0.upload(m0));
   HIP_TRY(c->mat1.upload(m1));
   HIP_TRY(c->sph0.upload(sp0));
@@ -399,7 +396,7 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
   HIP_TRY(c->light3.upload(l3));
 
   rtx::SceneDev& d = c->scene;
-  d.nodes = c->nodes.p; d.tri0 = c->tri0.p; d.tri1 = c->tri1.p; d.tri2 = c->tri2.p; d.tri3 = c->tri3.p;
+  d.nodes = c->nodes.p; d.tris = c->tris.p;
   d.mat0 = c->mat0.p; d.mat1 = c->mat1.p;
   d.sph0 = c->sph0.p; d.sph1 = c->sph1.p; d.sph2 = c->sph2.p;
   d.box0 = c->box0.p; d.box1 = c->box1.p; d.pln0 = c->pln0.p; d.pln1 = c->pln1.p;
