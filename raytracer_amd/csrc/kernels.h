@@ -93,8 +93,9 @@ struct Queue {
 };
 
 struct ShadowQueue {
-  float4* q0;  // (d.xyz, tfar = distance - eps)
-  float4* q1;  // (contribution.rgb, destination slot bits)
+  float4* q0;  // (o.xyz, tfar = distance - eps)
+  float4* q1;  // (d.xyz, destination slot bits)
+  float4* q2;  // (contribution.rgb, 0): read only for segments found unoccluded
 };
 
 // Per-segment counters, one 128-byte line per segment.  c[q] packs the fill of
@@ -149,9 +150,11 @@ enum TraceMode {
 // Per-lane traversal stack: the first lds_entries entries live in LDS (one column
 // per lane, `stride` ints apart); deeper entries, which a well-built tree needs
 // only for rare rays, go to a global array with one column per launched thread.
+typedef __attribute__((address_space(3))) int* lds_int_ptr;
+typedef __attribute__((address_space(1))) int* global_int_ptr;
 struct Stack {
-  int* lds;
-  int* spill;
+  lds_int_ptr lds;        // explicit address spaces: no flat-aperture tests in the walk
+  global_int_ptr spill;
   int stride;          // LDS column stride (threads per block)
   int lds_entries;
   uint32_t spill_stride;  // threads per launch
@@ -324,8 +327,8 @@ struct Node4Test {
   bool hit[4];
 };
 __device__ __forceinline__ float ubyte_f(uint32_t w, int i) { return (float)((w >> (8 * i)) & 0xffu); }
-__device__ __forceinline__ Node4Test test_node4(const float4* nd, f3 o, f3 inv, float tmax, int4& refs) {
-  float4 q0 = nd[0], q1f = nd[1], q2f = nd[2], q3f = nd[3];
+__device__ __forceinline__ Node4Test test_node4(float4 q0, float4 q1f, float4 q2f, float4 q3f, f3 o, f3 inv,
+                                                float tmax, int4& refs) {
   const uint32_t ew = __float_as_uint(q0.w);
   const float ax = __uint_as_float((ew & 0xffu) << 23) * inv.x;
   const float ay = __uint_as_float(((ew >> 8) & 0xffu) << 23) * inv.y;
@@ -418,7 +421,8 @@ __device__ __forceinline__ void closest_nodes(const Geom& g, const Stack& stk, W
   if (MODE == kGlobalBvh4) {
     while (w.cur >= 0) {
       int4 refs;
-      Node4Test nt = test_node4(g.nodes + 4 * (size_t)w.cur, w.o, w.inv, best.t, refs);
+      const float4* nd = g.nodes + 4 * (size_t)w.cur;
+      Node4Test nt = test_node4(nd[0], nd[1], nd[2], nd[3], w.o, w.inv, best.t, refs);
       float t0 = nt.hit[0] ? nt.tn[0] : INFINITY, t1 = nt.hit[1] ? nt.tn[1] : INFINITY;
       float t2 = nt.hit[2] ? nt.tn[2] : INFINITY, t3 = nt.hit[3] ? nt.tn[3] : INFINITY;
       int r0 = refs.x, r1 = refs.y, r2 = refs.z, r3 = refs.w;
@@ -475,7 +479,8 @@ __device__ __forceinline__ void any_nodes(const Geom& g, const Stack& stk, Walk&
   if (MODE == kGlobalBvh4) {
     while (w.cur >= 0) {
       int4 refs;
-      Node4Test nt = test_node4(g.nodes + 4 * (size_t)w.cur, w.o, w.inv, tfar, refs);
+      const float4* nd = g.nodes + 4 * (size_t)w.cur;
+      Node4Test nt = test_node4(nd[0], nd[1], nd[2], nd[3], w.o, w.inv, tfar, refs);
       int next = kTraversalDone;
       if (nt.hit[3]) next = refs.w;
       if (nt.hit[2]) {
@@ -523,6 +528,112 @@ __device__ __forceinline__ void any_leaves(const Geom& g, const Stack& stk, floa
   }
 }
 
+// Single-phase walk for the wide tree in global memory, where every step waits on a
+// fetch: nodes and triangles are both 64-byte records, so each iteration fetches
+// the one record its lane stands on, whichever kind, and all lanes wait once.  A
+// lane at an inner node then tests its four children, a lane at a leaf tests one
+// triangle (a leaf of two takes two iterations).  Lanes no longer wait through
+// whole node or leaf phases of the others.
+// (The address is formed as an integer and the loads go through a global-address-space
+// pointer: both arrays are device allocations in this mode.)
+typedef float fvec4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) fvec4* global_rec;
+__device__ __forceinline__ global_rec record_of(const Geom& g, int cur) {
+  const uint32_t leaf = ~(uint32_t)cur;
+  const uintptr_t a = cur >= 0 ? (uintptr_t)g.nodes + 64u * (uintptr_t)(uint32_t)cur
+                               : (uintptr_t)g.tris + 64u * (uintptr_t)(leaf >> 3);
+  return (global_rec)a;
+}
+__device__ __forceinline__ float4 as_float4(fvec4 v) { return make_float4(v.x, v.y, v.z, v.w); }
+// After one triangle of leaf word `leaf`: the rest of the leaf, or the next stack entry.
+__device__ __forceinline__ int after_triangle(uint32_t leaf, const Stack& stk, int& sp) {
+  const uint32_t more = leaf & 7u;
+  if (more != 0) return (int)~((((leaf >> 3) + 1u) << 3) | (more - 1u));
+  return sp == 0 ? (int)kTraversalDone : stk.pop(sp);
+}
+__device__ __forceinline__ void closest_step(const Geom& g, const Stack& stk, float eps, Walk& w,
+                                             ClosestHit& best) {
+  {
+    global_rec rec = record_of(g, w.cur);
+    const float4 q0 = as_float4(rec[0]), q1 = as_float4(rec[1]), q2 = as_float4(rec[2]), q3 = as_float4(rec[3]);
+    if (w.cur >= 0) {
+      int4 refs;
+      Node4Test nt = test_node4(q0, q1, q2, q3, w.o, w.inv, best.t, refs);
+      float t0 = nt.hit[0] ? nt.tn[0] : INFINITY, t1 = nt.hit[1] ? nt.tn[1] : INFINITY;
+      float t2 = nt.hit[2] ? nt.tn[2] : INFINITY, t3 = nt.hit[3] ? nt.tn[3] : INFINITY;
+      int r0 = refs.x, r1 = refs.y, r2 = refs.z, r3 = refs.w;
+      order2(t0, r0, t1, r1);
+      order2(t2, r2, t3, r3);
+      order2(t0, r0, t2, r2);
+      order2(t1, r1, t3, r3);
+      order2(t1, r1, t2, r2);
+      if (t0 < INFINITY) {
+        if (t3 < INFINITY) stk.push(w.sp, r3);
+        if (t2 < INFINITY) stk.push(w.sp, r2);
+        if (t1 < INFINITY) stk.push(w.sp, r1);
+        w.cur = r0;
+      } else {
+        w.cur = w.sp == 0 ? kTraversalDone : stk.pop(w.sp);
+      }
+    } else {
+      const uint32_t leaf = ~(uint32_t)w.cur;
+      const float t = tri_intersect_n(mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q2.x, q2.y, q2.z),
+                                      mk3(q3.x, q3.y, q3.z), w.o, w.d);
+      const uint32_t prim = __float_as_uint(q0.w);
+      if (eps < t && t < INFINITY && (t < best.t || (t == best.t && prim < best.prim))) {
+        best.t = t;
+        best.prim = prim;
+        best.slot = leaf >> 3;
+      }
+      w.cur = after_triangle(leaf, stk, w.sp);
+    }
+  }
+}
+__device__ __forceinline__ void closest_single_phase(const Geom& g, const Stack& stk, float eps, Walk& w,
+                                                     ClosestHit& best) {
+  while (w.cur != kTraversalDone) closest_step(g, stk, eps, w, best);
+}
+__device__ __forceinline__ void any_step(const Geom& g, const Stack& stk, float eps, float tfar, Walk& w,
+                                         bool& hit) {
+  {
+    global_rec rec = record_of(g, w.cur);
+    const float4 q0 = as_float4(rec[0]), q1 = as_float4(rec[1]), q2 = as_float4(rec[2]), q3 = as_float4(rec[3]);
+    if (w.cur >= 0) {
+      int4 refs;
+      Node4Test nt = test_node4(q0, q1, q2, q3, w.o, w.inv, tfar, refs);
+      int next = kTraversalDone;
+      if (nt.hit[3]) next = refs.w;
+      if (nt.hit[2]) {
+        if (next != kTraversalDone) stk.push(w.sp, next);
+        next = refs.z;
+      }
+      if (nt.hit[1]) {
+        if (next != kTraversalDone) stk.push(w.sp, next);
+        next = refs.y;
+      }
+      if (nt.hit[0]) {
+        if (next != kTraversalDone) stk.push(w.sp, next);
+        next = refs.x;
+      }
+      w.cur = next != kTraversalDone ? next : (w.sp == 0 ? kTraversalDone : stk.pop(w.sp));
+    } else {
+      const uint32_t leaf = ~(uint32_t)w.cur;
+      const float t = tri_intersect_n(mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q2.x, q2.y, q2.z),
+                                      mk3(q3.x, q3.y, q3.z), w.o, w.d);
+      hit = eps < t && t < tfar;
+      if (hit)
+        w.cur = kTraversalDone;
+      else
+        w.cur = after_triangle(leaf, stk, w.sp);
+    }
+  }
+}
+__device__ __forceinline__ bool any_single_phase(const Geom& g, const Stack& stk, float eps, float tfar, Walk& w) {
+  bool hit = false;
+  while (w.cur != kTraversalDone) any_step(g, stk, eps, tfar, w, hit);
+  return hit;
+}
+
 // Closest mesh hit of one ray per lane.
 template <int MODE>
 __device__ __forceinline__ void mesh_closest(const SceneDev& sc, const Geom& g, f3 o, f3 d, const Stack& stk,
@@ -530,9 +641,13 @@ __device__ __forceinline__ void mesh_closest(const SceneDev& sc, const Geom& g, 
   ClosestHit best = {INFINITY, kMiss, kMiss};
   Walk w;
   walk_begin<MODE>(sc, o, d, w);
-  while (w.cur != kTraversalDone) {
-    closest_nodes<MODE>(g, stk, w, best);
-    closest_leaves<MODE>(g, stk, sc.eps, w, best);
+  if constexpr (MODE == kGlobalBvh4) {
+    closest_single_phase(g, stk, sc.eps, w, best);
+  } else {
+    while (w.cur != kTraversalDone) {
+      closest_nodes<MODE>(g, stk, w, best);
+      closest_leaves<MODE>(g, stk, sc.eps, w, best);
+    }
   }
   best_t = best.t;
   best_slot = best.slot;
@@ -544,12 +659,16 @@ __device__ __forceinline__ bool mesh_any(const SceneDev& sc, const Geom& g, f3 o
                                          const Stack& stk) {
   Walk w;
   walk_begin<MODE>(sc, o, d, w);
-  bool hit = false;
-  while (w.cur != kTraversalDone) {
-    any_nodes<MODE>(g, stk, w, tfar);
-    any_leaves<MODE>(g, stk, sc.eps, tfar, w, hit);
+  if constexpr (MODE == kGlobalBvh4) {
+    return any_single_phase(g, stk, sc.eps, tfar, w);
+  } else {
+    bool hit = false;
+    while (w.cur != kTraversalDone) {
+      any_nodes<MODE>(g, stk, w, tfar);
+      any_leaves<MODE>(g, stk, sc.eps, tfar, w, hit);
+    }
+    return hit;
   }
-  return hit;
 }
 
 // The analytic objects of Scene::castRay (reference Scene.h:164-188): spheres in
@@ -1079,29 +1198,47 @@ struct TraceParams {
 #define RTX_TRACE_PROLOGUE()                                                                  \
   extern __shared__ float4 lds_dyn[];                                                         \
   Stack stk;                                                                                  \
-  stk.lds = reinterpret_cast<int*>(lds_dyn) + threadIdx.x;                                    \
+  stk.lds = (lds_int_ptr)(reinterpret_cast<int*>(lds_dyn) + threadIdx.x);                                    \
   stk.stride = BLOCK;                                                                         \
   stk.lds_entries = tp.lds_entries;                                                           \
   stk.spill_stride = tp.spill_stride;                                                         \
-  stk.spill = tp.spill + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * BLOCK + threadIdx.x); \
+  stk.spill = (global_int_ptr)(tp.spill + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * BLOCK + threadIdx.x)); \
   const Geom geom = MODE == kLdsBvh2 ? stage_geom_lds(sc, lds_dyn + (tp.lds_entries * BLOCK) / 4, \
                                                       threadIdx.x, BLOCK)                     \
                                      : global_geom(sc)
+
+// Which (segment, block within the segment) this workgroup serves.  Workgroups are
+// handed to the eight XCDs round-robin by linear id, and each XCD has its own L2:
+// the mapping gives every block of segment s to XCD s mod 8.  A segment holds the
+// paths of a compact run of pixels, bounce after bounce, so its rays meet the same
+// part of the tree and one L2 keeps that part, instead of eight L2s each keeping
+// the same mixture.
+struct SegBlock {
+  uint32_t s, x;
+};
+__device__ __forceinline__ SegBlock seg_block() {
+  const uint32_t nseg = gridDim.y, gx = gridDim.x;
+  if (nseg & 7u) return {blockIdx.y, blockIdx.x};
+  const uint32_t id = blockIdx.y * gx + blockIdx.x;
+  const uint32_t xcd = id & 7u, k = id >> 3, per = nseg >> 3;
+  return {(k % per) * 8u + xcd, k / per};
+}
 
 template <int BLOCK, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_intersect(SceneDev sc, Queue q, uint2* hits,
                                                      const SegCounter* seg, int qi, uint32_t cap,
                                                      TraceParams tp) {
-  const uint32_t s = blockIdx.y;
+  const SegBlock sb = MODE == kGlobalBvh4 ? seg_block() : SegBlock{blockIdx.y, blockIdx.x};
+  const uint32_t s = sb.s;
   const uint32_t n = seg_paths(seg[s].c[qi]);
-  if (blockIdx.x * BLOCK >= n) return;  // the whole block is beyond the fill: skip the staging too
+  if (sb.x * BLOCK >= n) return;  // the whole block is beyond the fill: skip the staging too
   RTX_TRACE_PROLOGUE();
   // Block-stride loop over the segment: a block that staged the scene in LDS
   // amortises that over several batches of rays.
   // The next batch's ray is loaded before the current one is traced, so the HBM
   // latency of the load hides behind the traversal.
   const uint32_t stride = gridDim.x * BLOCK;
-  uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+  uint32_t j = sb.x * BLOCK + threadIdx.x;
   float4 a = make_float4(0, 0, 0, 0);
   float2 b = make_float2(0, 0);
   if (j < n) {
@@ -1124,6 +1261,89 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(SceneDev sc, Queue q, uint2
     a = an;
     b = bn;
     j = jn;
+  }
+}
+
+// Lanes of a wave idle at once before the wave stops to hand them new rays.
+#ifndef RTX_REFILL_LANES
+#define RTX_REFILL_LANES 8
+#endif
+constexpr uint32_t kRefillLanes = RTX_REFILL_LANES;
+constexpr uint32_t kNoRay = 0xffffffffu;
+
+// k_intersect for the wide tree in global memory.  A wave owns `rays_per_wave`
+// consecutive rays of its segment and keeps its 64 lanes supplied from them: in the
+// single-phase walk a lane whose ray has ended would only idle until the longest ray
+// of the wave ends (4 of 5 lanes on the 1 M-triangle mesh), so it stores its hit and
+// takes the next unassigned ray instead.  The next 64 unassigned rays sit prefetched
+// in registers (lane L holds ray next+L) and are handed out with lane shuffles.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_intersect_wide(SceneDev sc, Queue q, uint2* hits,
+                                                          const SegCounter* seg, int qi, uint32_t cap,
+                                                          uint32_t rays_per_wave, TraceParams tp) {
+  constexpr int MODE = kGlobalBvh4;
+  const SegBlock sb = seg_block();
+  const uint32_t s = sb.s;
+  const uint32_t n = seg_paths(seg[s].c[qi]);
+  constexpr uint32_t kWaves = BLOCK / 64;
+  if (sb.x * kWaves * rays_per_wave >= n) return;
+  RTX_TRACE_PROLOGUE();
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t first = (sb.x * kWaves + wave) * rays_per_wave;
+  const uint32_t w_end = first + rays_per_wave < n ? first + rays_per_wave : n;
+  uint32_t next = first < n ? first : n;
+  const size_t base = (size_t)s * cap;
+
+  float4 pa = make_float4(0, 0, 0, 0);
+  float2 pb = make_float2(0, 0);
+  if (next + lane < w_end) {
+    pa = q.r0[base + next + lane];
+    pb = q.r1[base + next + lane];
+  }
+  Walk w;
+  w.o = w.d = w.inv = mk3(0, 0, 0);
+  w.cur = kTraversalDone;
+  w.sp = 0;
+  ClosestHit best = {INFINITY, kMiss, kMiss};
+  uint32_t ri = kNoRay;
+  for (;;) {
+    const bool walking = w.cur != kTraversalDone;
+    const unsigned long long wm = __ballot(walking);
+    const uint32_t idle = 64u - (uint32_t)__popcll(wm);
+    if (wm == 0 || (idle >= kRefillLanes && next < w_end)) {  // wave-uniform
+      const unsigned long long im = ~wm;
+      const uint32_t rank =
+          __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
+      // every lane shuffles (a shuffle reads nothing from a lane that is switched off)
+      const float ax = __shfl(pa.x, (int)rank), ay = __shfl(pa.y, (int)rank), az = __shfl(pa.z, (int)rank);
+      const float aw = __shfl(pa.w, (int)rank), bx = __shfl(pb.x, (int)rank), by = __shfl(pb.y, (int)rank);
+      if (!walking) {
+        if (ri != kNoRay) {
+          float t = best.t;
+          uint32_t id = best.slot;
+          analytic_closest(sc, w.o, w.d, t, id);
+          hits[base + ri] = make_uint2(__float_as_uint(t), id);
+        }
+        const uint32_t j = next + rank;
+        ri = kNoRay;
+        if (j < w_end) {
+          ri = j;
+          walk_begin<MODE>(sc, mk3(ax, ay, az), mk3(aw, bx, by), w);
+          best.t = INFINITY;
+          best.prim = kMiss;
+          best.slot = kMiss;
+        }
+      }
+      next += idle;
+      next = next < w_end ? next : w_end;
+      if (next + lane < w_end) {
+        pa = q.r0[base + next + lane];
+        pb = q.r1[base + next + lane];
+      }
+      if (__ballot(ri != kNoRay) == 0) break;
+    }
+    if (w.cur != kTraversalDone) closest_step(geom, stk, sc.eps, w, best);
   }
 }
 
@@ -1154,9 +1374,21 @@ __global__ __launch_bounds__(256) void k_shade(SceneDev sc, Queue in, Queue out,
   if (alive) store_path(out, s * cap + pos, use_depth, p);
   if (want_shadow) {
     const uint32_t k = s * cap + spos;
-    sq.q0[k] = make_float4(sr.d.x, sr.d.y, sr.d.z, sr.tfar);
-    sq.q1[k] = make_float4(sr.contrib.x, sr.contrib.y, sr.contrib.z, __uint_as_float(s * cap + pos));
+    sq.q0[k] = make_float4(p.o.x, p.o.y, p.o.z, sr.tfar);
+    sq.q1[k] = make_float4(sr.d.x, sr.d.y, sr.d.z, __uint_as_float(s * cap + pos));
+    sq.q2[k] = make_float4(sr.contrib.x, sr.contrib.y, sr.contrib.z, 0.0f);
   }
+}
+
+// An unoccluded NEE segment adds its contribution to the colour of its path.
+__device__ __forceinline__ void add_contribution(const Queue& paths, const ShadowQueue& sq, uint32_t k,
+                                                 uint32_t slot) {
+  float4 c = sq.q2[k];
+  float4 s1 = paths.s1[slot];
+  s1.x += c.x;
+  s1.y += c.y;
+  s1.z += c.z;
+  paths.s1[slot] = s1;
 }
 
 // Traces the NEE segments queued by k_shade; an unoccluded one adds its
@@ -1165,24 +1397,17 @@ template <int BLOCK, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_shadow(SceneDev sc, Queue paths, ShadowQueue sq,
                                                   const SegCounter* seg, int q_out, uint32_t cap,
                                                   TraceParams tp) {
-  const uint32_t s = blockIdx.y;
+  const SegBlock sb = MODE == kGlobalBvh4 ? seg_block() : SegBlock{blockIdx.y, blockIdx.x};
+  const uint32_t s = sb.s;
   const uint32_t n = seg_shadow(seg[s].c[q_out]);
-  if (blockIdx.x * BLOCK >= n) return;
+  if (sb.x * BLOCK >= n) return;
   RTX_TRACE_PROLOGUE();
-  for (uint32_t j = blockIdx.x * BLOCK + threadIdx.x; j < n; j += gridDim.x * BLOCK) {
+  for (uint32_t j = sb.x * BLOCK + threadIdx.x; j < n; j += gridDim.x * BLOCK) {
     const uint32_t k = s * cap + j;
     float4 a = sq.q0[k];
     float4 b = sq.q1[k];
-    const uint32_t slot = __float_as_uint(b.w);
-    float4 r0 = paths.r0[slot];
-    bool occ = occluded<MODE>(sc, geom, mk3(r0.x, r0.y, r0.z), mk3(a.x, a.y, a.z), a.w, stk);
-    if (!occ) {
-      float4 s1 = paths.s1[slot];
-      s1.x += b.x;
-      s1.y += b.y;
-      s1.z += b.z;
-      paths.s1[slot] = s1;
-    }
+    bool occ = occluded<MODE>(sc, geom, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), a.w, stk);
+    if (!occ) add_contribution(paths, sq, k, __float_as_uint(b.w));
   }
 }
 

@@ -100,7 +100,7 @@ struct rtx_ctx {
   DevBuf<int> spill;           // stack entries beyond stack_entries, one column per launched thread
 
   // path pool
-  DevBuf<float4> r0[2], s0[2], s1[2], sq0, sq1;
+  DevBuf<float4> r0[2], s0[2], s1[2], sq0, sq1, sq2;
   DevBuf<float2> r1[2];
   DevBuf<uint2> s2[2], hits;
   DevBuf<uint32_t> depth[2];
@@ -163,7 +163,7 @@ void free_ctx(rtx_ctx* c) {
     c->r0[i].release(); c->r1[i].release(); c->s0[i].release(); c->s1[i].release();
     c->s2[i].release(); c->depth[i].release();
   }
-  c->sq0.release(); c->sq1.release(); c->hits.release(); c->seg.release(); c->sum.release(); c->spill.release();
+  c->sq0.release(); c->sq1.release(); c->sq2.release(); c->hits.release(); c->seg.release(); c->sum.release(); c->spill.release();
   c->resolve_tmp.release(); c->res.release();
   if (c->h_sum) (void)hipHostFree(c->h_sum);
   for (int i = 0; i < kPollSlots; i++)
@@ -254,6 +254,7 @@ int rtx_create(const rtx_config* cfg, rtx_ctx** out) {
   }
   CTX_TRY(c->sq0.alloc(pool));
   CTX_TRY(c->sq1.alloc(pool));
+  CTX_TRY(c->sq2.alloc(pool));
   CTX_TRY(c->hits.alloc(pool));
   CTX_TRY(c->seg.alloc(nseg));
   CTX_TRY(c->sum.alloc(1));
@@ -459,6 +460,11 @@ int rtx_get_scene_info(rtx_ctx* c, rtx_scene_info* out) {
 
 namespace {
 
+// k_intersect_wide: rays a wave owns at most (measured best of 64..2048 on the 1 M-triangle
+// mesh), and the number of waves a launch should still have.
+constexpr uint32_t kRaysPerWaveMax = 256;
+constexpr unsigned long long kWaveSlotsTarget = 16384;
+
 enum StageKind { kGen = 0, kIsect = 1, kShade = 2, kShadow = 3, kFinish = 4, kReduce = 5, kOther = 6 };
 
 // Records start/stop events around a launch when profiling is on.
@@ -502,7 +508,7 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
   const unsigned long long total = (unsigned long long)rp.band_pixels * spp;
   rtx::SegCounter* seg = c->seg.p;
   rtx::Summary* sum = c->sum.p;
-  rtx::ShadowQueue sq{c->sq0.p, c->sq1.p};
+  rtx::ShadowQueue sq{c->sq0.p, c->sq1.p, c->sq2.p};
   const int use_depth = c->cfg.max_bounces ? 1 : 0;
   const size_t scene_lds = c->trace_mode == rtx::kLdsBvh2 ? c->lds_scene_bytes : 0;
   const size_t lds = (size_t)c->stack_entries * kTraceBlock * sizeof(int) + scene_lds;
@@ -556,9 +562,19 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
     uint32_t gx128 = div_up(seg_max_upper, kTraceBlock);
     gx128 = std::max(1u, std::min(gx128, div_up(gx128, kTraceBatches)));
     const uint32_t gx256 = div_up(seg_max_upper, 256);
+    // Wide tree, closest hit: waves own runs of rays and refill their lanes.  Long runs keep the lanes
+    // busy, but the launch still has to cover the chip's wave slots a few times over.
+    uint32_t rpw = 64;
+    while (rpw < kRaysPerWaveMax && (unsigned long long)active_upper / (2 * rpw) >= kWaveSlotsTarget) rpw *= 2;
+    const uint32_t gxi = std::max(1u, div_up(seg_max_upper, rpw * (kTraceBlock / 64)));
     lt.begin(kIsect, active_upper);
-    RTX_BY_MODE(c->trace_mode, rtx::k_intersect, kTraceBlock, (dim3(gx128, nseg), kTraceBlock, lds, st),
-                (c->scene, qc, c->hits.p, seg, cur, cap, tp));
+    if (c->trace_mode == rtx::kGlobalBvh4) {
+      rtx::k_intersect_wide<kTraceBlock><<<dim3(gxi, nseg), kTraceBlock, lds, st>>>(c->scene, qc, c->hits.p, seg, cur,
+                                                                                    cap, rpw, tp);
+    } else {
+      RTX_BY_MODE(c->trace_mode, rtx::k_intersect, kTraceBlock, (dim3(gx128, nseg), kTraceBlock, lds, st),
+                  (c->scene, qc, c->hits.p, seg, cur, cap, tp));
+    }
     lt.end();
     lt.begin(kShade, active_upper);
     rtx::k_shade<<<dim3(gx256, nseg), 256, 0, st>>>(c->scene, qc, qn, sq, c->hits.p, seg, cur, cap, c->res.p);
