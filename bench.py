@@ -170,6 +170,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:
+        # Communicator set-up (RCCL builds its rings on the first collective) stays outside
+        # the timed region whatever --warmup is.
+        if args.backend == "nccl":
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        dist.barrier()
     for _ in range(args.warmup):
         step()
     fence()
