@@ -249,7 +249,7 @@ def main():
                                    (f", {args.tiles} row bands" if args.tiles > 1 else ""),
                        "triangles": int(info.num_triangles), "spheres": int(info.num_spheres),
                        "lights": int(info.num_lights), "bvh_nodes": int(info.num_nodes),
-                       "pool_paths": int(args.pool) or (1 << 23)},
+                       "pool_paths": int(args.pool) or (1 << 24)},
             "time_to_image_ms": round(elapsed / args.steps * 1e3, 3),
             "mpaths_per_s": round(paths / elapsed / 1e6, 2),
             "bounces_per_path": round(bounces / max(paths, 1), 3),

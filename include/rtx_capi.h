@@ -97,7 +97,7 @@ typedef struct {
   float focal_length, lens_radius; /* thin lens */
   float stretch_x, stretch_y;      /* orthogonal */
   int32_t device;        /* HIP device ordinal; -1 = the calling thread's current device */
-  uint32_t pool_paths;   /* capacity of the in-flight path pool; 0 = library default (8 Mi paths) */
+  uint32_t pool_paths;   /* capacity of the in-flight path pool; 0 = library default (16 Mi paths) */
   uint32_t finish_paths; /* once the samples are exhausted and at most this many paths are left, they
                             are run to their end by one launch (one path per lane) instead of further
                             rounds of small kernels; 0 = library default (131072), 1 = never */

@@ -39,7 +39,7 @@ int fail_hip(hipError_t e, const char* what) {
     if (e_ != hipSuccess) return fail_hip(e_, #expr);  \
   } while (0)
 
-constexpr uint32_t kDefaultPool = 1u << 23;      // 8 Mi paths in flight: 2 queues * 64 B + hits + shadow = 1.4 GB
+constexpr uint32_t kDefaultPool = 1u << 24;      // 16 Mi paths in flight: 2 queues * 64 B + hits + shadow = 3.1 GB
 constexpr uint32_t kDefaultFinish = 1u << 17;    // at most this many paths left: finish them in one launch
 constexpr uint32_t kDefaultResultMiB = 8192;     // per-sample result buffer budget
 constexpr uint32_t kSegmentTarget = 8192;        // aim for this many slots per queue segment
