@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--pool", type=int, default=0, help="in-flight path pool (0 = library default)")
+    ap.add_argument("--finish-paths", type=int, default=0, help="drain-kernel threshold (0 = library default)")
     ap.add_argument("--strong", action="store_true", help="split the workload's spp across ranks instead")
     ap.add_argument("--tiles", type=int, default=1,
                     help="row bands: ranks form TILES groups, group g renders band g of the frame and the "
@@ -145,7 +146,8 @@ def main():
         base = replica * (spp_full // replicas) + min(replica, spp_full % replicas)
     else:
         spp, base = spp_full, replica * spp_full
-    cfg = Config(width=W, height=H, sky=wl["sky"], device=local_rank, pool_paths=args.pool)
+    cfg = Config(width=W, height=H, sky=wl["sky"], device=local_rank, pool_paths=args.pool,
+                 finish_paths=args.finish_paths)
     sc = wl["scene"]()
 
     r = Renderer(cfg)

@@ -100,7 +100,7 @@ typedef struct {
   uint32_t pool_paths;   /* capacity of the in-flight path pool; 0 = library default (16 Mi paths) */
   uint32_t finish_paths; /* once the samples are exhausted and at most this many paths are left, they
                             are run to their end by one launch (one path per lane) instead of further
-                            rounds of small kernels; 0 = library default (131072), 1 = never */
+                            rounds of small kernels; 0 = library default (524288), 1 = never */
   uint32_t result_buffer_mib; /* budget of the per-sample result buffer (12 bytes per sample); a call
                             with more samples is rendered in several chunks; 0 = default (8192) */
 } rtx_config;

@@ -40,7 +40,7 @@ int fail_hip(hipError_t e, const char* what) {
   } while (0)
 
 constexpr uint32_t kDefaultPool = 1u << 24;      // 16 Mi paths in flight: 2 queues * 64 B + hits + shadow = 3.1 GB
-constexpr uint32_t kDefaultFinish = 1u << 17;    // at most this many paths left: finish them in one launch
+constexpr uint32_t kDefaultFinish = 1u << 19;    // at most this many paths left: finish them in one launch
 constexpr uint32_t kDefaultResultMiB = 8192;     // per-sample result buffer budget
 constexpr uint32_t kSegmentTarget = 8192;        // aim for this many slots per queue segment
 constexpr uint32_t kMaxSegments = 512;
