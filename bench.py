@@ -60,9 +60,10 @@ def pmc_traffic(workload, kernel):
     Counters cannot be read from inside this process, so the figure comes from the file."""
     path = os.path.join(ROOT, "profiles", f"pmc_traffic_{workload}.json")
     try:
-        k = json.load(open(path))["kernels"][kernel]
-        return round(k["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT)
-    except (OSError, KeyError, ValueError):
+        kernels = json.load(open(path))["kernels"]
+        name = next(k for k in sorted(kernels) if k.startswith(kernel))  # k_shade -> k_shade_wave_append, ...
+        return round(kernels[name]["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT)
+    except (OSError, KeyError, ValueError, StopIteration):
         return None, None
 
 

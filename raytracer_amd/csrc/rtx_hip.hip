@@ -577,7 +577,12 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
     }
     lt.end();
     lt.begin(kShade, active_upper);
-    rtx::k_shade<<<dim3(gx256, nseg), 256, 0, st>>>(c->scene, qc, qn, sq, c->hits.p, seg, cur, cap, c->res.p);
+    if (shadows)
+      rtx::k_shade_block_append<<<dim3(gx256, nseg), 256, 0, st>>>(c->scene, qc, qn, sq, c->hits.p, seg, cur, cap,
+                                                                  c->res.p);
+    else
+      rtx::k_shade_wave_append<<<dim3(gx256, nseg), 256, 0, st>>>(c->scene, qc, qn, sq, c->hits.p, seg, cur, cap,
+                                                                 c->res.p);
     lt.end();
     launches += 2;
     if (shadows) {
