@@ -17,11 +17,12 @@ __global__ __launch_bounds__(256) void copy4(const float4* a, float4* b, size_t 
 
 struct Q { float4* r0; float2* r1; float4* s0; float4* s1; uint2* s2; };
 
-// MODE bits: 1 compact by wave, 2 read all state, 4 no result writes, 8 result planes, 16 compact by block
+// MODE bits: 1 compact by wave, 2 read all state, 4 no result writes, 8 result planes, 16 compact by block,
+// 32 every lane writes a result (no holes in the result lines)
 template <int MODE>
 __global__ __launch_bounds__(256) void shade_like(Q in, Q out, const uint2* hits, float* res, unsigned long long* counters,
                                                   uint32_t cap, uint32_t keep_mod, size_t n_total) {
-  constexpr bool COMPACT = MODE & 1, READ_STATE = MODE & 2, NO_RES = MODE & 4, PLANES = MODE & 8, BLOCKC = MODE & 16;
+  constexpr bool COMPACT = MODE & 1, READ_STATE = MODE & 2, NO_RES = MODE & 4, PLANES = MODE & 8, BLOCKC = MODE & 16, ALLRES = MODE & 32;
   __shared__ uint32_t wave_cnt[4];
   __shared__ uint32_t block_base;
   const uint32_t s = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
@@ -57,7 +58,8 @@ __global__ __launch_bounds__(256) void shade_like(Q in, Q out, const uint2* hits
   if (keep) {
     const uint32_t o = s * cap + pos;
     out.r0[o] = r0; out.r1[o] = r1; out.s0[o] = s0; out.s1[o] = s1; out.s2[o] = s2;
-  } else if (!NO_RES) {
+  }
+  if ((ALLRES || !keep) && !NO_RES) {
     if (PLANES) {
       res[s2.x] = s1.x; res[n_total + s2.x] = s1.y; res[2 * n_total + s2.x] = s1.z;
     } else {
@@ -106,6 +108,7 @@ int main() {
       {1 | 8, 42, "wave-compacted, result planes"},
       {16, 42, "block-compacted, results AoS"},
       {16 | 8, 42, "block-compacted, result planes"},
+      {1 | 32, 42, "wave-compacted, every lane writes a result"},
       {1 | 4, 100, "keep all, wave atomic, no results"},
       {4, 100, "keep all, in place, no results"},
       {1, 78, "wave-compacted keep 78%, results AoS"},
@@ -114,7 +117,7 @@ int main() {
   for (const V& v : vs) {
     const double f = v.keep / 100.0;
     const double rd = (v.mode & 2) ? 72 : 40 + 32 * 0.5;
-    const double wr = f * 64 + ((v.mode & 4) ? 0 : (1 - f) * 12);
+    const double wr = f * 64 + ((v.mode & 4) ? 0 : (v.mode & 32) ? 12 : (1 - f) * 12);
     auto go = [&](auto tag) {
       timeit(v.name, n * (rd + wr), [&] { shade_like<decltype(tag)::value><<<grid, 256>>>(q[0], q[1], hits, res, ctr, cap, v.keep, n); });
     };
@@ -127,6 +130,7 @@ int main() {
       case 16: go(std::integral_constant<int, 16>{}); break;
       case 24: go(std::integral_constant<int, 24>{}); break;
       case 4: go(std::integral_constant<int, 4>{}); break;
+      case 33: go(std::integral_constant<int, 33>{}); break;
     }
   }
   return 0;
