@@ -13,7 +13,9 @@
  *     oracle/_ref/libref_pcg.so (see oracle/Makefile) and against the golden
  *     vectors generated from that build (tests/golden/pcg_kat.json).
  *   - Oven-box radiance (closed room, emission 0.5, albedo 0.5 -> 1.0):
- *     PINNED to the analytic answer stated at Raytracer.cpp:203-214.
+ *     PINNED to the analytic answer stated at Raytracer.cpp:203-214; the same room
+ *     with a glass and a mirror sphere of albedo 1 inside keeps that answer and
+ *     pins the energy balance of the specular branches and of Russian roulette.
  *   - Everything else (Vec3/Matrix3 arithmetic, camera, triangle/sphere
  *     intersection, castRay/isOccluded rules, light sampling, pathTrace):
  *     PARITY UNPINNED.  Vec3.h includes SFML and Scene.h/Obj.h include Embree 3;

@@ -169,6 +169,18 @@ def oven(emission=0.5, albedo=0.5) -> SceneData:
     return SceneData(tris, np.zeros(len(tris), np.uint32), mats, name="oven")
 
 
+def oven_objects() -> SceneData:
+    """The oven with a glass and a mirror sphere inside.  Both have albedo 1 and no emission, and
+    the integrator follows them with weight 1 (Integrator.h:198-205,248-278), so the radiance is
+    still emission / (1 - albedo) = 1.0 everywhere: an analytic answer that exercises the
+    specular branches, Russian roulette at the 0.99 cap and long chains inside the glass."""
+    base = oven()
+    sph = [sphere((-0.5, 0.6, 0.5), 0.5, material((1, 1, 1), 0.0, SPECULAR)),
+           sphere((0.7, 0.8, 0.0), 0.6, material((1, 1, 1), 0.0, REFLECTIVE))]
+    return SceneData(base.triangles, base.material_index, base.materials, np.array(sph, SPHERE_DTYPE),
+                     name="oven_objects")
+
+
 def reference_scene(i: int) -> SceneData:
     """The reference's commented-out analytic scenes (Raytracer.cpp:180-226): planes, spheres and
     axis-aligned boxes only, no mesh (so no NEE: the light list holds mesh triangles only).

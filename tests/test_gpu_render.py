@@ -100,9 +100,11 @@ def test_converged_image_parity(oracle, rtx_lib):
     assert cross <= 1.25 * noise, (cross, noise)
 
 
-@pytest.mark.parametrize("make", [scenes.oven, lambda: scenes.reference_scene(2)], ids=["triangles", "planes"])
+@pytest.mark.parametrize("make", [scenes.oven, lambda: scenes.reference_scene(2), scenes.oven_objects],
+                         ids=["triangles", "planes", "glass_and_mirror_inside"])
 def test_oven_box_is_one(make, rtx_lib):
-    """The reference's oven test (Raytracer.cpp:203-214), from triangles and from its six planes."""
+    """The reference's oven test (Raytracer.cpp:203-214), from triangles, from its six planes, and
+    with a glass and a mirror sphere of albedo 1 inside (the answer stays 1.0)."""
     cfg = Config(width=64, height=64)
     spp = 256
     got, st, _ = gpu_render(cfg, make(), spp)

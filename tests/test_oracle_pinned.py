@@ -83,3 +83,13 @@ def test_oven_box_converges_to_one(oracle):
     assert st.nee_samples == 0 and st.nan_paths == 0
     # expected bounces: survive with p = 0.5 each time -> about 2 per path, plus the first hit
     assert 2.5 < st.bounces / st.paths < 3.5
+
+
+def test_oven_with_glass_and_mirror_is_still_one(oracle):
+    """Specular objects of albedo 1 leave the closed room's radiance at emission/(1-albedo) = 1.0."""
+    cfg = Config(width=32, height=32)
+    spp = 256
+    img, st = oracle.OracleScene(scenes.oven_objects(), cfg).render(spp)
+    img = img / spp
+    assert abs(img.mean() - 1.0) < 0.01, img.mean()
+    assert st.nee_samples == 0 and st.nan_paths == 0
