@@ -6,9 +6,12 @@
 //
 //   k_plan       queue bookkeeping: how many new samples each segment takes
 //   k_generate   primary rays for new samples         (Raytracer.cpp:246-250, Camera.h)
-//   k_intersect  closest hit: BVH2 + spheres          (Scene.h:144-189)
-//   k_shade      emission/MIS, Russian roulette, BRDF sampling, NEE set-up,
-//                compaction of the survivors           (Integrator.h:98-291)
+//   k_intersect  closest hit: tree + analytic objects (Scene.h:144-189); two-child tree
+//                staged in LDS for small scenes, k_intersect_wide on the four-child
+//                quantised tree in global memory for large ones
+//   k_shade_*    emission/MIS, Russian roulette, BRDF sampling, NEE set-up,
+//                compaction of the survivors           (Integrator.h:98-291);
+//                one append per wave or per block
 //   k_shadow     any-hit for the NEE segments          (Scene.h:191-225)
 //   k_finish     runs the last few paths to their end, one path per lane
 //   k_reduce     adds the per-sample results to the per-pixel sums, in sample order
@@ -19,7 +22,7 @@
 //   s0 float4 (attenuation.rgb, mis_brdf_pdf)
 //   s1 float4 (colour.rgb, nee_pdf)    s2 uint2  (sample ordinal, rng state)
 // There are two such queues; k_shade reads one and appends the surviving paths
-// to the other (ballot + mbcnt prefix, one atomic per wave).
+// to the other (ballot + mbcnt prefix, one atomic per wave or block).
 //
 // Each queue is cut into `nseg` segments of `cap` slots with a counter of their
 // own (one per 128-byte line): a wave appends to the segment it read from, so a
@@ -45,7 +48,7 @@ constexpr uint32_t kMiss = 0xffffffffu;
 constexpr uint32_t kSphereBit = 0x80000000u;
 // Traversal cursor value for "nothing left".  It cannot collide with a leaf
 // reference: ~0x80000000 would be a leaf of 8 triangles at slot 2^28-1, and the
-// builder makes leaves of at most 4.
+// builder makes leaves of at most 2.
 constexpr int kTraversalDone = (int)0x80000000u;
 
 struct SceneDev {
