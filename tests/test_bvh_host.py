@@ -95,7 +95,7 @@ def test_empty_mesh_has_no_nodes(probe):
 
 
 def test_flat_bvh_walk_equals_linear_scan(probe, oracle):
-    """Traversing the product's tree on the CPU (same slab rule as the kernels) with the
+XX
     oracle's triangle test gives the oracle's linear-scan answer."""
     from raytracer_amd.capi import Config
     sc = scenes.soup(1500, 0, seed=8)
