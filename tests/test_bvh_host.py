@@ -95,8 +95,8 @@ def test_empty_mesh_has_no_nodes(probe):
 
 
 def test_flat_bvh_walk_equals_linear_scan(probe, oracle):
-XX
-    oracle's triangle test gives the oracle's linear-scan answer."""
+    """Traversing the product's tree on the CPU (plain slab test in float, with the kernels'
+    visiting rule) with the oracle's triangle test gives the oracle's linear-scan answer."""
     from raytracer_amd.capi import Config
     sc = scenes.soup(1500, 0, seed=8)
     nodes, order, depth = build(probe, sc.triangles)
