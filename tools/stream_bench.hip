@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
@@ -66,6 +67,50 @@ __global__ __launch_bounds__(256) void shade_like(Q in, Q out, const uint2* hits
       float* d = res + 3 * (size_t)s2.x;
       d[0] = s1.x; d[1] = s1.y; d[2] = s1.z;
     }
+  }
+}
+
+// The same job with the path state in two arrays of 32-byte records instead of five arrays:
+// R = (o, d, ordinal, rng), S = (attenuation, mis, colour, nee).
+struct Q2 { float4* R; float4* S; };
+template <bool BLOCKC, bool NO_RES>
+__global__ __launch_bounds__(256) void shade_like_rec(Q2 in, Q2 out, const uint2* hits, float* res,
+                                                      unsigned long long* counters, uint32_t cap, uint32_t keep_mod) {
+  __shared__ uint32_t wave_cnt[4];
+  __shared__ uint32_t block_base;
+  const uint32_t s = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t i = s * cap + j;
+  float4 ra = in.R[2 * (size_t)i], rb = in.R[2 * (size_t)i + 1];
+  uint2 h = hits[i];
+  float4 sa = in.S[2 * (size_t)i], sb = in.S[2 * (size_t)i + 1];
+  const uint32_t rngbits = __float_as_uint(rb.w), ordinal = __float_as_uint(rb.z);
+  const bool keep = ((rngbits >> 3) % 100) < keep_mod;
+  ra.x += h.x * 1e-30f; sb.x += rb.x * sa.x;
+  const unsigned long long m = __ballot(keep);
+  uint32_t pos;
+  if (BLOCKC) {
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) wave_cnt[w] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0)
+      block_base = (uint32_t)atomicAdd(&counters[16 * s], (unsigned long long)(wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3]));
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t k = 0; k < w; k++) before += wave_cnt[k];
+    pos = block_base + before + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+  } else {
+    uint32_t base = 0;
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if (lane == 0) base = (uint32_t)atomicAdd(&counters[16 * s], (unsigned long long)__popcll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+  }
+  if (keep) {
+    const size_t o = (size_t)s * cap + pos;
+    out.R[2 * o] = ra; out.R[2 * o + 1] = rb; out.S[2 * o] = sa; out.S[2 * o + 1] = sb;
+  } else if (!NO_RES) {
+    float* d = res + 3 * (size_t)ordinal;
+    d[0] = sb.x; d[1] = sb.y; d[2] = sb.z;
   }
 }
 
@@ -131,6 +176,28 @@ int main() {
       case 24: go(std::integral_constant<int, 24>{}); break;
       case 4: go(std::integral_constant<int, 4>{}); break;
       case 33: go(std::integral_constant<int, 33>{}); break;
+    }
+  }
+  {
+    Q2 a, b;
+    CHECK(hipMalloc(&a.R, n * 32)); CHECK(hipMalloc(&a.S, n * 32)); CHECK(hipMalloc(&b.R, n * 32)); CHECK(hipMalloc(&b.S, n * 32));
+    CHECK(hipMemset(a.S, 0, n * 32));
+    float4* hr = (float4*)malloc(n * 32);
+    for (size_t i = 0; i < n; i++) {
+      hr[2 * i] = make_float4(0, 0, 0, 0);
+      float fx, fy; memcpy(&fx, &h2[i].x, 4); memcpy(&fy, &h2[i].y, 4);
+      hr[2 * i + 1] = make_float4(0, 0, fx, fy);
+    }
+    CHECK(hipMemcpy(a.R, hr, n * 32, hipMemcpyHostToDevice));
+    for (uint32_t keep : {42u, 78u, 100u}) {
+      const double f = keep / 100.0;
+      char name[128];
+      snprintf(name, 128, "32-byte records, wave-compacted keep %u%%, results", keep);
+      timeit(name, n * (72 + f * 64 + (1 - f) * 12), [&] { shade_like_rec<false, false><<<grid, 256>>>(a, b, hits, res, ctr, cap, keep); });
+      snprintf(name, 128, "32-byte records, block-compacted keep %u%%, results", keep);
+      timeit(name, n * (72 + f * 64 + (1 - f) * 12), [&] { shade_like_rec<true, false><<<grid, 256>>>(a, b, hits, res, ctr, cap, keep); });
+      snprintf(name, 128, "32-byte records, wave-compacted keep %u%%, no results", keep);
+      timeit(name, n * (72 + f * 64), [&] { shade_like_rec<false, true><<<grid, 256>>>(a, b, hits, res, ctr, cap, keep); });
     }
   }
   return 0;
