@@ -1,0 +1,64 @@
+"""GPU parity on randomly drawn small cases: odd image sizes, tiny pools (many refills and
+segments that run dry), scenes on both sides of the LDS/global-tree switch, analytic objects
+mixed in, the three cameras.  The normals integrator has no trigonometry (thin lens aside), so
+its image must match the oracle bit for bit; one path-traced sample per pixel must match to the per-path bar
+of test_gpu_render.py."""
+import numpy as np
+import pytest
+
+from raytracer_amd import scenes
+from raytracer_amd.capi import Config, Renderer
+
+pytestmark = pytest.mark.gpu
+
+
+def random_case(seed):
+    rng = np.random.default_rng(seed)
+    ntri = int(rng.choice([1, 2, 5, 40, 157, 158, 400, 3000]))
+    nsph = int(rng.integers(0, 4))
+    sc = scenes.soup(ntri, nsph, seed=seed + 100, size=float(rng.uniform(0.05, 0.6)))
+    if rng.random() < 0.5:
+        sc.boxes = np.array([scenes.box_obj(rng.uniform(-1, 0, 3) + [0, 1, 0], rng.uniform(0.1, 0.8, 3) + [0, 1, 0],
+                                            scenes.material((0.7, 0.7, 0.7)))], scenes.BOX_DTYPE)
+    if rng.random() < 0.5:
+        sc.planes = np.array([scenes.plane_obj((0, -0.5, 0), (0, 1, 0), scenes.material((0.5, 0.5, 0.5)))],
+                             scenes.PLANE_DTYPE)
+    cam = int(rng.integers(0, 3))
+    cfg = dict(width=int(rng.integers(3, 90)), height=int(rng.integers(3, 70)), sky=int(rng.integers(0, 2)),
+               camera=cam, fov=60.0 if cam == 1 else 50.0, pool_paths=int(rng.choice([256, 700, 4096, 1 << 15])),
+               finish_paths=int(rng.choice([0, 1, 64])), max_bounces=int(rng.choice([0, 0, 5])))
+    return sc, cfg
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_case(seed, oracle, rtx_lib):
+    sc, kw = random_case(seed)
+    spp = 1 + seed % 3
+    # normals: bit-exact (sums of up to three samples: the additions are ordered by sample index on both sides)
+    cfg = Config(integrator=1, **kw)
+    want, ost = oracle.OracleScene(sc, cfg).render(spp)
+    with Renderer(cfg) as r:
+        info = r.set_scene(sc)
+        acc = r.accum_alloc()
+        r.render(acc, spp)
+        got = r.resolve(acc, 1)
+        st = r.stats()
+    if kw["camera"] == 1:  # the thin lens samples its aperture with sinf/cosf (Camera.h:29-30): last-ulp differences
+        assert np.mean(np.all(np.abs(got - want) <= 1e-5 + 1e-3 * np.abs(want), axis=-1)) >= 0.98
+    else:
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (seed, kw, info.bvh_width)
+        assert st.bounces == ost.bounces
+    assert st.paths == ost.paths
+    # path tracing, one sample per pixel
+    cfg = Config(integrator=0, **kw)
+    want, ost = oracle.OracleScene(sc, cfg).render(1)
+    with Renderer(cfg) as r:
+        r.set_scene(sc)
+        acc = r.accum_alloc()
+        r.render(acc, 1)
+        got = r.resolve(acc, 1)
+        st = r.stats()
+    ok = np.all(np.abs(got - want) <= 1e-5 + 1e-3 * np.abs(want), axis=-1) | ~np.isfinite(want).all(-1)
+    assert ok.mean() >= 0.98, (seed, kw, float(ok.mean()))
+    assert np.array_equal(np.isfinite(got).all(-1), np.isfinite(want).all(-1)) or ok.mean() >= 0.98
+    assert abs(st.bounces - ost.bounces) <= max(0.02 * ost.bounces, 20)
