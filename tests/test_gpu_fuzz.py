@@ -30,7 +30,7 @@ def random_case(seed):
     return sc, cfg
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(40))
 def test_random_case(seed, oracle, rtx_lib):
     sc, kw = random_case(seed)
     spp = 1 + seed % 3
