@@ -1228,7 +1228,7 @@ __device__ __forceinline__ SegBlock seg_block() {
 }
 
 template <int BLOCK, int MODE>
-__global__ __launch_bounds__(BLOCK) void k_intersect(SceneDev sc, Queue q, uint2* hits,
+__global__ __launch_bounds__(BLOCK, MODE == kGlobalBvh2 ? 4 : 8) void k_intersect(SceneDev sc, Queue q, uint2* hits,
                                                      const SegCounter* seg, int qi, uint32_t cap,
                                                      TraceParams tp) {
   const SegBlock sb = MODE == kGlobalBvh4 ? seg_block() : SegBlock{blockIdx.y, blockIdx.x};
@@ -1281,7 +1281,7 @@ constexpr uint32_t kNoRay = 0xffffffffu;
 // takes the next unassigned ray instead.  The next 64 unassigned rays sit prefetched
 // in registers (lane L holds ray next+L) and are handed out with lane shuffles.
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_intersect_wide(SceneDev sc, Queue q, uint2* hits,
+__global__ __launch_bounds__(BLOCK, 7) void k_intersect_wide(SceneDev sc, Queue q, uint2* hits,
                                                           const SegCounter* seg, int qi, uint32_t cap,
                                                           uint32_t rays_per_wave, TraceParams tp) {
   constexpr int MODE = kGlobalBvh4;
@@ -1461,7 +1461,7 @@ __device__ __forceinline__ void add_contribution(const Queue& paths, const Shado
 // Traces the NEE segments queued by k_shade; an unoccluded one adds its
 // contribution to the colour of the path it belongs to (Integrator.h:217-223).
 template <int BLOCK, int MODE>
-__global__ __launch_bounds__(BLOCK) void k_shadow(SceneDev sc, Queue paths, ShadowQueue sq,
+__global__ __launch_bounds__(BLOCK, 8) void k_shadow(SceneDev sc, Queue paths, ShadowQueue sq,
                                                   const SegCounter* seg, int q_out, uint32_t cap,
                                                   TraceParams tp) {
   const SegBlock sb = MODE == kGlobalBvh4 ? seg_block() : SegBlock{blockIdx.y, blockIdx.x};
