@@ -874,6 +874,62 @@ __device__ __forceinline__ void wave_append(bool take_path, bool take_shadow, bo
 // ----------------------------------------------------------------------------
 // One bounce of pathTrace.
 
+// The primary ray of the k-th sample generated in a render call (reference
+// Raytracer.cpp:246-250: two jitter draws, camera ray, ray.o += pos).  Sample k is
+// sample index sample_base + k / band_pixels of pixel (k mod band_pixels) of the
+// band, so consecutive lanes take consecutive pixels.  The random stream of a sample
+// depends only on (pixel, sample index, seed); `rng` returns its state after the
+// camera's draws.  A pure function of k: a kernel can recompute a fresh path's ray
+// instead of reading it back (see Primary).
+__device__ __forceinline__ void primary_ray(const CameraDev& cam, const RenderParams& rp, uint32_t k, f3& o, f3& d,
+                                            uint32_t& rng) {
+  const uint32_t in_band = k % rp.band_pixels;
+  const uint32_t sample = rp.sample_base + k / rp.band_pixels;
+  const uint32_t pixel = rp.row0 * cam.width + in_band;
+  const uint32_t px = pixel % cam.width, py = pixel / cam.width;
+  rng = pcg_hash(pixel ^ pcg_hash(sample ^ pcg_hash(rp.seed32)));
+  float jx = pcg_uniform(rng);
+  float jy = pcg_uniform(rng);
+  float fx = (float)(int)px + jx - 0.5f;
+  float fy = (float)(int)py + jy - 0.5f;
+  const float W = (float)cam.width, H = (float)cam.height;
+  o = mk3(cam.ox, cam.oy, cam.oz);
+  if (cam.type == 2) {  // OrthogonalCamera, Camera.h:73-79
+    o = vadd(o, mk3((2.0f * fx - W) / W * cam.stretch_x, -(2.0f * fy - H) / H * cam.stretch_y, 0.f));
+    d = mk3(0.0f, 0.0f, -1.0f);
+  } else {
+    float x = (2.0f * fx - W) / W * cam.tan_x;
+    float y = (2.0f * fy - H) / H * cam.tan_y;
+    if (cam.type == 0) {  // PerspectiveCamera, Camera.h:18-25
+      d = vnormalized(mk3(x, -y, -1.0f));
+    } else {  // ThinLensCamera, Camera.h:44-57
+      d = mk3(x, -y, -1.0f);
+      float t = -cam.focal_length / d.z;
+      f3 focal = vadd(o, vscale(d, t));
+      float r = pcg_uniform(rng);
+      float theta = (float)((double)(pcg_uniform(rng) * 2) * 3.14159265358979323846);
+      float sn, cs;
+      sincosf(theta, &sn, &cs);
+      o = vadd(o, vscale(mk3(r * cs, r * sn, 0.0f), cam.lens_radius));
+      d = vnormalized(vsub(focal, o));
+    }
+  }
+  o = vadd(o, mk3(cam.offx, cam.offy, cam.offz));
+}
+
+// How the kernels get at the fresh paths of a queue (slots gen_slot0.. of every
+// segment, filled since the last round).  With `recompute` set there is no k_generate
+// launch: nothing is stored for a fresh path, and k_intersect, k_shade and k_finish
+// each recompute its ray from its sample number.  That trades about a hundred
+// instructions per use for 32 bytes written and 24 + 32 bytes read back per fresh
+// path, on kernels that wait on memory.  Otherwise k_generate has written ray,
+// ordinal and generator state, and they are loaded.
+struct Primary {
+  CameraDev cam;
+  RenderParams rp;
+  int recompute;
+};
+
 struct PathState {
   f3 o, d, att, col;
   float mis_pdf, nee_pdf;
@@ -889,25 +945,31 @@ struct ShadowReq {
 // pathTrace starts with (Integrator.h:99-106); k_generate does not write them
 // and they are not read back (32 of the 64 bytes, on the most numerous paths).
 __device__ __forceinline__ void load_path(const Queue& q, uint32_t i, bool use_depth, bool fresh,
-                                          PathState& p) {
-  float4 r0 = q.r0[i];
-  float2 r1 = q.r1[i];
-  uint2 s2 = q.s2[i];
+                                          const Primary& pr, uint32_t fresh_k, PathState& p) {
   float4 s0 = make_float4(1.0f, 1.0f, 1.0f, -1.0f);
   float4 s1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  if (!fresh) {
-    s0 = q.s0[i];
-    s1 = q.s1[i];
+  if (fresh && pr.recompute) {
+    primary_ray(pr.cam, pr.rp, fresh_k, p.o, p.d, p.rng);
+    p.ordinal = fresh_k;
+    p.depth = 0;
+  } else {
+    float4 r0 = q.r0[i];
+    float2 r1 = q.r1[i];
+    uint2 s2 = q.s2[i];
+    if (!fresh) {
+      s0 = q.s0[i];
+      s1 = q.s1[i];
+    }
+    p.o = mk3(r0.x, r0.y, r0.z);
+    p.d = mk3(r0.w, r1.x, r1.y);
+    p.ordinal = s2.x;
+    p.rng = s2.y;
+    p.depth = use_depth ? q.depth[i] : 0;
   }
-  p.o = mk3(r0.x, r0.y, r0.z);
-  p.d = mk3(r0.w, r1.x, r1.y);
   p.att = mk3(s0.x, s0.y, s0.z);
   p.mis_pdf = s0.w;
   p.col = mk3(s1.x, s1.y, s1.z);
   p.nee_pdf = s1.w;
-  p.ordinal = s2.x;
-  p.rng = s2.y;
-  p.depth = use_depth ? q.depth[i] : 0;
 }
 __device__ __forceinline__ void store_path(const Queue& q, uint32_t i, bool use_depth, const PathState& p) {
   q.r0[i] = make_float4(p.o.x, p.o.y, p.o.z, p.d.x);
@@ -1049,7 +1111,8 @@ __device__ __forceinline__ void store_result(float* res, uint32_t ordinal, f3 co
 // ----------------------------------------------------------------------------
 // Kernels.
 
-__global__ void k_begin(SegCounter* seg, Summary* sum, uint32_t nseg, unsigned long long total_samples) {
+__global__ void k_begin(SegCounter* seg, Summary* sum, uint32_t nseg, unsigned long long total_samples,
+                        Primary pr, Primary* pr_out) {
   uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s < nseg) {
     seg[s].c[0] = 0;
@@ -1059,6 +1122,7 @@ __global__ void k_begin(SegCounter* seg, Summary* sum, uint32_t nseg, unsigned l
     seg[s].gen_ordinal0 = 0;
   }
   if (s == 0) {
+    *pr_out = pr;  // camera and sample numbering of this call, for the kernels that recompute primary rays
     sum->next_sample = 0;
     sum->total_samples = total_samples;
     sum->stat_paths = sum->stat_bounces = sum->stat_nee = sum->stat_shadow = 0;
@@ -1137,50 +1201,17 @@ __global__ __launch_bounds__(1024) void k_plan(SegCounter* seg, Summary* sum, in
   }
 }
 
-// Writes primary rays for the samples k_plan assigned to each segment (reference
-// Raytracer.cpp:246-250: two jitter draws, camera ray, ray.o += pos).  Sample
-// ordinal k maps to pixel (k mod band_pixels) of the band and sample index
-// sample_base + k / band_pixels, so consecutive lanes take consecutive pixels.
-// The random stream of a sample depends only on (pixel, sample index, seed).
+// Writes the primary rays of the samples k_plan assigned to each segment (used when
+// the kernels do not recompute them, see Primary).
 __global__ __launch_bounds__(256) void k_generate(Queue q, const SegCounter* seg, CameraDev cam,
                                                   RenderParams rp, int use_depth) {
   const uint32_t s = blockIdx.y;
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= seg[s].gen_count) return;
   const uint32_t ordinal = (uint32_t)(seg[s].gen_ordinal0 + j);
-  const uint32_t in_band = ordinal % rp.band_pixels;
-  const uint32_t sample = rp.sample_base + ordinal / rp.band_pixels;
-  const uint32_t pixel = rp.row0 * cam.width + in_band;
-  const uint32_t px = pixel % cam.width, py = pixel / cam.width;
-  uint32_t rng = pcg_hash(pixel ^ pcg_hash(sample ^ pcg_hash(rp.seed32)));
-  float jx = pcg_uniform(rng);
-  float jy = pcg_uniform(rng);
-  float fx = (float)(int)px + jx - 0.5f;
-  float fy = (float)(int)py + jy - 0.5f;
-  const float W = (float)cam.width, H = (float)cam.height;
-  f3 o = mk3(cam.ox, cam.oy, cam.oz);
-  f3 d;
-  if (cam.type == 2) {  // OrthogonalCamera, Camera.h:73-79
-    o = vadd(o, mk3((2.0f * fx - W) / W * cam.stretch_x, -(2.0f * fy - H) / H * cam.stretch_y, 0.f));
-    d = mk3(0.0f, 0.0f, -1.0f);
-  } else {
-    float x = (2.0f * fx - W) / W * cam.tan_x;
-    float y = (2.0f * fy - H) / H * cam.tan_y;
-    if (cam.type == 0) {  // PerspectiveCamera, Camera.h:18-25
-      d = vnormalized(mk3(x, -y, -1.0f));
-    } else {  // ThinLensCamera, Camera.h:44-57
-      d = mk3(x, -y, -1.0f);
-      float t = -cam.focal_length / d.z;
-      f3 focal = vadd(o, vscale(d, t));
-      float r = pcg_uniform(rng);
-      float theta = (float)((double)(pcg_uniform(rng) * 2) * 3.14159265358979323846);
-      float sn, cs;
-      sincosf(theta, &sn, &cs);
-      o = vadd(o, vscale(mk3(r * cs, r * sn, 0.0f), cam.lens_radius));
-      d = vnormalized(vsub(focal, o));
-    }
-  }
-  o = vadd(o, mk3(cam.offx, cam.offy, cam.offz));
+  f3 o, d;
+  uint32_t rng;
+  primary_ray(cam, rp, ordinal, o, d, rng);
   // A fresh path: only the ray, the sample ordinal and the generator are stored
   // (see load_path).
   const uint32_t slot = s * rp.cap + seg[s].gen_slot0 + j;
@@ -1228,14 +1259,18 @@ __device__ __forceinline__ SegBlock seg_block() {
 }
 
 template <int BLOCK, int MODE>
-__global__ __launch_bounds__(BLOCK, MODE == kGlobalBvh2 ? 4 : 8) void k_intersect(SceneDev sc, Queue q, uint2* hits,
-                                                     const SegCounter* seg, int qi, uint32_t cap,
-                                                     TraceParams tp) {
+__global__ __launch_bounds__(BLOCK, MODE == kGlobalBvh2 ? 4 : 7) void k_intersect(SceneDev sc, Queue q, uint2* hits,
+                                                                             const SegCounter* seg, int qi,
+                                                                             uint32_t cap, TraceParams tp,
+                                                                             const Primary* __restrict__ prp) {
   const SegBlock sb = MODE == kGlobalBvh4 ? seg_block() : SegBlock{blockIdx.y, blockIdx.x};
   const uint32_t s = sb.s;
   const uint32_t n = seg_paths(seg[s].c[qi]);
   if (sb.x * BLOCK >= n) return;  // the whole block is beyond the fill: skip the staging too
   RTX_TRACE_PROLOGUE();
+  // Rays from this slot on are recomputed, not loaded.
+  const uint32_t computed0 = prp->recompute ? seg[s].gen_slot0 : 0xffffffffu;
+  const uint32_t k0 = (uint32_t)seg[s].gen_ordinal0;
   // Block-stride loop over the segment: a block that staged the scene in LDS
   // amortises that over several batches of rays.
   // The next batch's ray is loaded before the current one is traced, so the HBM
@@ -1244,7 +1279,7 @@ __global__ __launch_bounds__(BLOCK, MODE == kGlobalBvh2 ? 4 : 8) void k_intersec
   uint32_t j = sb.x * BLOCK + threadIdx.x;
   float4 a = make_float4(0, 0, 0, 0);
   float2 b = make_float2(0, 0);
-  if (j < n) {
+  if (j < n && j < computed0) {
     a = q.r0[s * cap + j];
     b = q.r1[s * cap + j];
   }
@@ -1253,13 +1288,18 @@ __global__ __launch_bounds__(BLOCK, MODE == kGlobalBvh2 ? 4 : 8) void k_intersec
     const uint32_t jn = j + stride;
     float4 an = a;
     float2 bn = b;
-    if (jn < n) {
+    if (jn < n && jn < computed0) {
       an = q.r0[s * cap + jn];
       bn = q.r1[s * cap + jn];
     }
+    f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
+    if (j >= computed0) {
+      uint32_t rng;
+      primary_ray(prp->cam, prp->rp, k0 + (j - computed0), o, d, rng);
+    }
     float t;
     uint32_t id;
-    cast_ray<MODE>(sc, geom, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), stk, t, id);
+    cast_ray<MODE>(sc, geom, o, d, stk, t, id);
     hits[i] = make_uint2(__float_as_uint(t), id);
     a = an;
     b = bn;
@@ -1354,7 +1394,7 @@ __global__ __launch_bounds__(BLOCK, 7) void k_intersect_wide(SceneDev sc, Queue 
 // segment of `out`, finished paths store their colour to their sample's slot.
 __global__ __launch_bounds__(256) void k_shade_wave_append(SceneDev sc, Queue in, Queue out, ShadowQueue sq,
                                                const uint2* hits, SegCounter* seg, int qi, uint32_t cap,
-                                               float* res) {
+                                               float* res, const Primary* __restrict__ prp) {
   const uint32_t s = blockIdx.y;
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n = seg_paths(seg[s].c[qi]);
@@ -1367,7 +1407,7 @@ __global__ __launch_bounds__(256) void k_shade_wave_append(SceneDev sc, Queue in
   ShadowReq sr;
   bool alive = false, want_shadow = false, did_nee = false;
   if (active) {
-    load_path(in, i, use_depth, j >= seg[s].gen_slot0, p);
+    load_path(in, i, use_depth, j >= seg[s].gen_slot0, *prp, (uint32_t)seg[s].gen_ordinal0 + (j - seg[s].gen_slot0), p);
     uint2 h = hits[i];
     alive = shade_bounce(sc, global_geom(sc), p, __uint_as_float(h.x), h.y, want_shadow, did_nee, sr);
     if (!alive) store_result(res, p.ordinal, p.col);
@@ -1388,7 +1428,7 @@ __global__ __launch_bounds__(256) void k_shade_wave_append(SceneDev sc, Queue in
 // streams, long runs), 2 % slower where most paths end at once (open scene, sky).
 __global__ __launch_bounds__(256) void k_shade_block_append(SceneDev sc, Queue in, Queue out, ShadowQueue sq,
                                                             const uint2* hits, SegCounter* seg, int qi,
-                                                            uint32_t cap, float* res) {
+                                                            uint32_t cap, float* res, const Primary* __restrict__ prp) {
   __shared__ uint32_t wave_counts[4][3];
   __shared__ unsigned long long block_old;
   const uint32_t s = blockIdx.y;
@@ -1403,7 +1443,7 @@ __global__ __launch_bounds__(256) void k_shade_block_append(SceneDev sc, Queue i
   ShadowReq sr;
   bool alive = false, want_shadow = false, did_nee = false;
   if (active) {
-    load_path(in, i, use_depth, j >= seg[s].gen_slot0, p);
+    load_path(in, i, use_depth, j >= seg[s].gen_slot0, *prp, (uint32_t)seg[s].gen_ordinal0 + (j - seg[s].gen_slot0), p);
     uint2 h = hits[i];
     alive = shade_bounce(sc, global_geom(sc), p, __uint_as_float(h.x), h.y, want_shadow, did_nee, sr);
     if (!alive) store_result(res, p.ordinal, p.col);
@@ -1486,7 +1526,7 @@ constexpr uint32_t kFinishCap = 65536;
 template <int BLOCK, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_finish(SceneDev sc, Queue q, const SegCounter* seg, int qi,
                                                   uint32_t cap, float* res, Summary* sum,
-                                                  TraceParams tp) {
+                                                  TraceParams tp, const Primary* __restrict__ prp) {
   RTX_TRACE_PROLOGUE();
   const uint32_t s = blockIdx.y;
   const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
@@ -1494,7 +1534,8 @@ __global__ __launch_bounds__(BLOCK) void k_finish(SceneDev sc, Queue q, const Se
   uint32_t nb = 0, nn = 0, ns = 0;
   if (active) {
     PathState p;
-    load_path(q, s * cap + j, sc.max_bounces != 0, j >= seg[s].gen_slot0, p);
+    load_path(q, s * cap + j, sc.max_bounces != 0, j >= seg[s].gen_slot0, *prp,
+              (uint32_t)seg[s].gen_ordinal0 + (j - seg[s].gen_slot0), p);
     for (uint32_t it = 0; it < kFinishCap; it++) {
       float t;
       uint32_t id;

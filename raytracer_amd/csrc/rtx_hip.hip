@@ -106,6 +106,7 @@ struct rtx_ctx {
   DevBuf<uint32_t> depth[2];
   DevBuf<rtx::SegCounter> seg;
   DevBuf<rtx::Summary> sum;
+  DevBuf<rtx::Primary> primary;  // written by k_begin at the start of every chunk
   rtx::Summary* h_sum = nullptr;  // pinned, kPollSlots entries
   hipEvent_t poll_ev[kPollSlots]{};
   DevBuf<float> resolve_tmp;
@@ -163,7 +164,7 @@ void free_ctx(rtx_ctx* c) {
     c->r0[i].release(); c->r1[i].release(); c->s0[i].release(); c->s1[i].release();
     c->s2[i].release(); c->depth[i].release();
   }
-  c->sq0.release(); c->sq1.release(); c->sq2.release(); c->hits.release(); c->seg.release(); c->sum.release(); c->spill.release();
+  c->sq0.release(); c->sq1.release(); c->sq2.release(); c->hits.release(); c->seg.release(); c->sum.release(); c->primary.release(); c->spill.release();
   c->resolve_tmp.release(); c->res.release();
   if (c->h_sum) (void)hipHostFree(c->h_sum);
   for (int i = 0; i < kPollSlots; i++)
@@ -258,6 +259,7 @@ int rtx_create(const rtx_config* cfg, rtx_ctx** out) {
   CTX_TRY(c->hits.alloc(pool));
   CTX_TRY(c->seg.alloc(nseg));
   CTX_TRY(c->sum.alloc(1));
+  CTX_TRY(c->primary.alloc(1));
   CTX_TRY(hipMemset(c->seg.p, 0, sizeof(rtx::SegCounter) * nseg));
   CTX_TRY(hipMemset(c->sum.p, 0, sizeof(rtx::Summary)));
   CTX_TRY(hipHostMalloc((void**)&c->h_sum, sizeof(rtx::Summary) * kPollSlots, hipHostMallocDefault));
@@ -518,14 +520,22 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
   LaunchTimer lt(c, st, timer);
   uint64_t launches = 0, iterations = 0;
 
-  rtx::k_begin<<<div_up(nseg, 256), 256, 0, st>>>(seg, sum, nseg, total);
+  // Fresh paths: recomputed by the kernels that need them, or written by k_generate (the thin
+  // lens draws sinf/cosf per sample, and the wide-tree kernel prefetches rays by the 64).
+  rtx::Primary pr{cam, rp, 0};
+  pr.recompute = c->trace_mode != rtx::kGlobalBvh4 && c->cfg.camera != 1;
+  const rtx::Primary* prp = c->primary.p;
+  rtx::k_begin<<<div_up(nseg, 256), 256, 0, st>>>(seg, sum, nseg, total, pr, c->primary.p);
   rtx::k_plan<<<1, 1024, 0, st>>>(seg, sum, 0, -1, nseg, cap);
   const uint32_t first = (uint32_t)std::min<unsigned long long>(total, pool);
-  lt.begin(kGen, first);
-  rtx::k_generate<<<dim3(div_up(std::min(first, cap), 256), nseg), 256, 0, st>>>(queue_of(c, 0), seg, cam, rp,
-                                                                              use_depth);
-  lt.end();
-  launches += 3;
+  launches += 2;
+  if (!pr.recompute) {
+    lt.begin(kGen, first);
+    rtx::k_generate<<<dim3(div_up(std::min(first, cap), 256), nseg), 256, 0, st>>>(queue_of(c, 0), seg, cam, rp,
+                                                                                use_depth);
+    lt.end();
+    launches++;
+  }
 
   int cur = 0;
   // What the host knows: upper bounds, refreshed from snapshots of the summary.
@@ -550,7 +560,7 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
       lt.begin(kFinish, active_upper);
       RTX_BY_MODE(c->trace_mode, rtx::k_finish, kFinishBlock,
                   (dim3(div_up(seg_max_upper, kFinishBlock), nseg), kFinishBlock, lds_fin, st),
-                  (c->scene, queue_of(c, cur), seg, cur, cap, c->res.p, sum, tp));
+                  (c->scene, queue_of(c, cur), seg, cur, cap, c->res.p, sum, tp, prp));
       lt.end();
       launches++;
       finished = true;
@@ -573,16 +583,16 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
                                                                                     cap, rpw, tp);
     } else {
       RTX_BY_MODE(c->trace_mode, rtx::k_intersect, kTraceBlock, (dim3(gx128, nseg), kTraceBlock, lds, st),
-                  (c->scene, qc, c->hits.p, seg, cur, cap, tp));
+                  (c->scene, qc, c->hits.p, seg, cur, cap, tp, prp));
     }
     lt.end();
     lt.begin(kShade, active_upper);
     if (shadows)
       rtx::k_shade_block_append<<<dim3(gx256, nseg), 256, 0, st>>>(c->scene, qc, qn, sq, c->hits.p, seg, cur, cap,
-                                                                  c->res.p);
+                                                                  c->res.p, prp);
     else
       rtx::k_shade_wave_append<<<dim3(gx256, nseg), 256, 0, st>>>(c->scene, qc, qn, sq, c->hits.p, seg, cur, cap,
-                                                                 c->res.p);
+                                                                 c->res.p, prp);
     lt.end();
     launches += 2;
     if (shadows) {
@@ -595,10 +605,12 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
     rtx::k_plan<<<1, 1024, 0, st>>>(seg, sum, nxt, cur, nseg, cap);
     launches++;
     if (left_upper > 0) {
-      lt.begin(kGen, (uint64_t)std::min<unsigned long long>(left_upper, pool));
-      rtx::k_generate<<<dim3(cap / 256, nseg), 256, 0, st>>>(qn, seg, cam, rp, use_depth);
-      lt.end();
-      launches++;
+      if (!pr.recompute) {
+        lt.begin(kGen, (uint64_t)std::min<unsigned long long>(left_upper, pool));
+        rtx::k_generate<<<dim3(cap / 256, nseg), 256, 0, st>>>(qn, seg, cam, rp, use_depth);
+        lt.end();
+        launches++;
+      }
       seg_max_upper = cap;  // the refill may top every segment up
       active_upper = pool;
     }
