@@ -153,22 +153,37 @@ def main():
 
     r = Renderer(cfg)
     info = r.set_scene(sc)
-    accum = torch.zeros(H * W * 3, dtype=torch.float32, device="cuda")
+    # Two sum buffers, used in turn: the RCCL reduce of one step runs on RCCL's stream while the
+    # next step renders into the other buffer.
+    accums = [torch.zeros(H * W * 3, dtype=torch.float32, device="cuda") for _ in range(2 if world > 1 else 1)]
+    accum = accums[0]
+    pending = [None] * len(accums)
     stream = torch.cuda.current_stream().cuda_stream
+    step_no = [0]
 
     def step():
-        accum.zero_()
-        r.render(accum, spp, sample_base=base, seed=0x5EED, row0=row0, row1=row1, stream=stream)
+        b = step_no[0] % len(accums)
+        step_no[0] += 1
+        if pending[b] is not None:  # the reduce that last read this buffer (two steps ago)
+            pending[b].wait()
+            pending[b] = None
+        buf = accums[b]
+        buf.zero_()
+        r.render(buf, spp, sample_base=base, seed=0x5EED, row0=row0, row1=row1, stream=stream)
         if world > 1:  # bands are disjoint and zero elsewhere: one sum serves tiles and sample ranges
             if args.backend == "nccl":
-                dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+                pending[b] = dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM, async_op=True)
             else:
-                host = accum.cpu()
+                host = buf.cpu()
                 dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
                 if rank == 0:
-                    accum.copy_(host)
+                    buf.copy_(host)
 
     def fence():
+        for b, p in enumerate(pending):
+            if p is not None:
+                p.wait()
+                pending[b] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
