@@ -637,11 +637,12 @@ __device__ __forceinline__ bool any_single_phase(const Geom& g, const Stack& stk
   return hit;
 }
 
-// Closest mesh hit of one ray per lane.
+// Closest mesh hit of one ray per lane among the hits with t <= t_limit (a hit at
+// exactly t_limit counts).  best_slot is kMiss, and best_t is t_limit, when there is none.
 template <int MODE>
 __device__ __forceinline__ void mesh_closest(const SceneDev& sc, const Geom& g, f3 o, f3 d, const Stack& stk,
-                                             float& best_t, uint32_t& best_slot) {
-  ClosestHit best = {INFINITY, kMiss, kMiss};
+                                             float t_limit, float& best_t, uint32_t& best_slot) {
+  ClosestHit best = {t_limit, kMiss, kMiss};
   Walk w;
   walk_begin<MODE>(sc, o, d, w);
   if constexpr (MODE == kGlobalBvh4) {
@@ -729,14 +730,24 @@ __device__ __forceinline__ bool analytic_any(const SceneDev& sc, f3 o, f3 d, flo
   return false;
 }
 
-// Scene::castRay, reference Scene.h:144-189: mesh first, then the spheres in
-// order (the first of equal t wins); the sphere wins only when strictly closer
-// than the mesh hit.  Returns t and an id: kMiss, kSphereBit|index, or triangle slot.
+// Scene::castRay, reference Scene.h:144-189: the closest mesh hit and the closest
+// analytic object (spheres in order, the first of equal t wins); the object wins only
+// when strictly closer than the mesh hit.  The objects are tested first here and the
+// tree is then walked for hits up to and including the object's distance, which gives
+// the same winner and spares most of the walk for rays that end on an object (every
+// bounce of a chain inside a glass sphere).  Returns t and an id: kMiss,
+// kSphereBit|index, or triangle slot.
 template <int MODE>
 __device__ __forceinline__ void cast_ray(const SceneDev& sc, const Geom& g, f3 o, f3 d, const Stack& stk,
                                          float& t_out, uint32_t& id_out) {
-  mesh_closest<MODE>(sc, g, o, d, stk, t_out, id_out);  // id: triangle slot, kMiss when t = inf
-  analytic_closest(sc, o, d, t_out, id_out);
+  float ts = INFINITY;
+  uint32_t sid = kMiss;
+  analytic_closest(sc, o, d, ts, sid);
+  float t;
+  uint32_t slot;
+  mesh_closest<MODE>(sc, g, o, d, stk, ts, t, slot);
+  t_out = t;  // = ts when the mesh has nothing at or before ts
+  id_out = slot != kMiss ? slot : sid;
 }
 
 // Scene::isOccluded, reference Scene.h:191-225, for a segment whose far end
@@ -1349,7 +1360,7 @@ __global__ __launch_bounds__(BLOCK, 7) void k_intersect_wide(SceneDev sc, Queue 
   w.cur = kTraversalDone;
   w.sp = 0;
   ClosestHit best = {INFINITY, kMiss, kMiss};
-  uint32_t ri = kNoRay;
+  uint32_t ri = kNoRay, object_id = kMiss;
   for (;;) {
     const bool walking = w.cur != kTraversalDone;
     const unsigned long long wm = __ballot(walking);
@@ -1362,18 +1373,16 @@ __global__ __launch_bounds__(BLOCK, 7) void k_intersect_wide(SceneDev sc, Queue 
       const float ax = __shfl(pa.x, (int)rank), ay = __shfl(pa.y, (int)rank), az = __shfl(pa.z, (int)rank);
       const float aw = __shfl(pa.w, (int)rank), bx = __shfl(pb.x, (int)rank), by = __shfl(pb.y, (int)rank);
       if (!walking) {
-        if (ri != kNoRay) {
-          float t = best.t;
-          uint32_t id = best.slot;
-          analytic_closest(sc, w.o, w.d, t, id);
-          hits[base + ri] = make_uint2(__float_as_uint(t), id);
-        }
+        if (ri != kNoRay)  // as cast_ray: the mesh hit if there is one at or before the object's distance
+          hits[base + ri] = make_uint2(__float_as_uint(best.t), best.slot != kMiss ? best.slot : object_id);
         const uint32_t j = next + rank;
         ri = kNoRay;
         if (j < w_end) {
           ri = j;
           walk_begin<MODE>(sc, mk3(ax, ay, az), mk3(aw, bx, by), w);
           best.t = INFINITY;
+          object_id = kMiss;
+          analytic_closest(sc, w.o, w.d, best.t, object_id);
           best.prim = kMiss;
           best.slot = kMiss;
         }
