@@ -161,8 +161,9 @@ struct Stack {
   int stride;          // LDS column stride (threads per block)
   int lds_entries;
   uint32_t spill_stride;  // threads per launch
+  bool all_in_lds;        // two-child trees: the host sized the LDS part for the deepest path
   __device__ __forceinline__ void push(int& sp, int v) const {
-    if (sp < lds_entries)
+    if (all_in_lds || sp < lds_entries)
       lds[sp * stride] = v;
     else
       spill[(size_t)(sp - lds_entries) * spill_stride] = v;
@@ -170,7 +171,7 @@ struct Stack {
   }
   __device__ __forceinline__ int pop(int& sp) const {
     sp--;
-    return sp < lds_entries ? lds[sp * stride] : spill[(size_t)(sp - lds_entries) * spill_stride];
+    return (all_in_lds || sp < lds_entries) ? lds[sp * stride] : spill[(size_t)(sp - lds_entries) * spill_stride];
   }
 };
 __device__ __forceinline__ Geom global_geom(const SceneDev& sc) {
@@ -1246,6 +1247,7 @@ struct TraceParams {
   stk.lds = (lds_int_ptr)(reinterpret_cast<int*>(lds_dyn) + threadIdx.x);                                    \
   stk.stride = BLOCK;                                                                         \
   stk.lds_entries = tp.lds_entries;                                                           \
+  stk.all_in_lds = MODE != kGlobalBvh4;                                                       \
   stk.spill_stride = tp.spill_stride;                                                         \
   stk.spill = (global_int_ptr)(tp.spill + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * BLOCK + threadIdx.x)); \
   const Geom geom = MODE == kLdsBvh2 ? stage_geom_lds(sc, lds_dyn + (tp.lds_entries * BLOCK) / 4, \
@@ -1270,7 +1272,7 @@ __device__ __forceinline__ SegBlock seg_block() {
 }
 
 template <int BLOCK, int MODE>
-__global__ __launch_bounds__(BLOCK, MODE == kGlobalBvh2 ? 4 : 7) void k_intersect(SceneDev sc, Queue q, uint2* hits,
+__global__ __launch_bounds__(BLOCK, MODE == kGlobalBvh2 ? 4 : 8) void k_intersect(SceneDev sc, Queue q, uint2* hits,
                                                                              const SegCounter* seg, int qi,
                                                                              uint32_t cap, TraceParams tp,
                                                                              const Primary* __restrict__ prp) {
