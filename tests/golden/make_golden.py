@@ -109,6 +109,9 @@ IMAGES = {
     "sample1": (lambda: scenes.sphere_sky(), 1),
     "sample2": (lambda: scenes.sphere_sky(glass=True), 1),
     "ref_scene0": (lambda: scenes.reference_scene(0), 1),
+    # scenes past the LDS limit: the four-child tree, k_generate, the refilling closest-hit kernel
+    "soup3k": (lambda: scenes.soup(3000, 3), 1),
+    "terrain40": (lambda: scenes.terrain(40), 0),
 }
 
 

@@ -23,6 +23,8 @@ SCENES = {
     "sample1": lambda: scenes.sphere_sky(),
     "sample2": lambda: scenes.sphere_sky(glass=True),
     "ref_scene0": lambda: scenes.reference_scene(0),
+    "soup3k": lambda: scenes.soup(3000, 3),
+    "terrain40": lambda: scenes.terrain(40),
 }
 
 
