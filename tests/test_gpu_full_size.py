@@ -47,3 +47,31 @@ def test_full_frame_against_oracle(name, make, sky, spp, oracle, rtx_lib):
     assert st.paths == ost.paths == 1024 * 1024 * spp
     assert abs(st.bounces - ost.bounces) <= 0.005 * ost.bounces
     assert abs(st.nee_samples - ost.nee_samples) <= 0.005 * max(ost.nee_samples, 1)
+
+
+def test_million_triangle_mesh_render_against_oracle(oracle, rtx_lib):
+    """The 1 M-triangle mesh of the bench (BASELINE configs[3]) at a reduced frame, 32 spp: same
+    bars as above.  The traversal itself is checked bit for bit in test_gpu_trace.py."""
+    cfg = Config(width=320, height=180, sky=0)
+    sc = scenes.terrain(707)
+    spp = 32
+    want, ost = oracle.OracleScene(sc, cfg).render(spp, seed=0x5EED, nthreads=16)
+    want = want / spp
+    with Renderer(cfg) as r:
+        info = r.set_scene(sc)
+        assert info.bvh_width == 4 and info.num_triangles > 990000
+        acc = r.accum_alloc()
+        r.render(acc, spp, seed=0x5EED)
+        got = r.resolve(acc, spp)
+        st = r.stats()
+        r.accum_clear(acc)
+        r.render(acc, spp, seed=0xBEEF)
+        other = r.resolve(acc, spp)
+    assert np.isfinite(got).all()
+    rmse = lambda a, b: float(np.sqrt(np.mean((a - b) ** 2)))
+    same, noise = rmse(got, want), rmse(other, want)
+    assert same <= 0.15 * noise, (same, noise)
+    assert abs(float(got.mean()) / float(want.mean()) - 1) < 0.005
+    assert abs(st.bounces - ost.bounces) <= 0.005 * ost.bounces
+    assert abs(st.shadow_rays - st.nee_samples) <= st.nee_samples  # shadow rays are a subset of the light samples
+    assert abs(st.nee_samples - ost.nee_samples) <= 0.005 * max(ost.nee_samples, 1)
