@@ -103,6 +103,10 @@ typedef struct {
                             rounds of small kernels; 0 = library default (524288), 1 = never */
   uint32_t result_buffer_mib; /* budget of the per-sample result buffer (12 bytes per sample); a call
                             with more samples is rendered in several chunks; 0 = default (8192) */
+  int32_t primary_rays;  /* how the kernels get the primary rays of new samples: 0 = the library chooses
+                            (recomputed from the sample number by each kernel that needs them where that
+                            is cheaper than a round trip through memory), 1 = always written by the
+                            generate kernel and read back.  Both give the same bits. */
 } rtx_config;
 
 /* Scene geometry, borrowed for the duration of rtx_set_scene.

@@ -186,6 +186,8 @@ int rtx_create(const rtx_config* cfg, rtx_ctx** out) {
     return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_create: bad image size");
   if (cfg->camera < 0 || cfg->camera > 2 || cfg->integrator < 0 || cfg->integrator > 1)
     return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_create: bad camera or integrator");
+  if (cfg->primary_rays < 0 || cfg->primary_rays > 1)
+    return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_create: bad primary_rays");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev == 0)
@@ -523,7 +525,7 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
   // Fresh paths: recomputed by the kernels that need them, or written by k_generate (the thin
   // lens draws sinf/cosf per sample, and the wide-tree kernel prefetches rays by the 64).
   rtx::Primary pr{cam, rp, 0};
-  pr.recompute = c->trace_mode != rtx::kGlobalBvh4 && c->cfg.camera != 1;
+  pr.recompute = c->cfg.primary_rays != 1 && c->trace_mode != rtx::kGlobalBvh4 && c->cfg.camera != 1;
   const rtx::Primary* prp = c->primary.p;
   rtx::k_begin<<<div_up(nseg, 256), 256, 0, st>>>(seg, sum, nseg, total, pr, c->primary.p);
   rtx::k_plan<<<1, 1024, 0, st>>>(seg, sum, 0, -1, nseg, cap);

@@ -135,6 +135,22 @@ def test_sample_ranges_row_bands_and_chunks_are_bit_identical(rtx_lib):
     assert st.nee_samples == st4.nee_samples and st.shadow_rays == st4.shadow_rays
 
 
+@pytest.mark.parametrize("camera", [0, 2], ids=["perspective", "orthogonal"])
+def test_recomputed_and_stored_primary_rays_give_the_same_bits(camera, rtx_lib):
+    """For LDS-resident scenes the kernels recompute the primary ray of a fresh path from its
+    sample number instead of reading what k_generate wrote (primary_rays = 0); primary_rays = 1
+    forces the stored form.  Same arithmetic, so the images and the counts are identical."""
+    for sc, sky in [(scenes.cornell(), 0), (scenes.sphere_sky(glass=True), 1)]:
+        kw = dict(width=200, height=120, sky=sky, camera=camera, pool_paths=1 << 13, max_bounces=0)
+        a, sa, _ = gpu_render(Config(primary_rays=0, **kw), sc, 6)
+        b, sb, _ = gpu_render(Config(primary_rays=1, **kw), sc, 6)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert (sa.paths, sa.bounces, sa.nee_samples, sa.shadow_rays) == (sb.paths, sb.bounces, sb.nee_samples, sb.shadow_rays)
+        c, sc_, _ = gpu_render(Config(primary_rays=0, **dict(kw, max_bounces=4)), sc, 3)
+        d, sd, _ = gpu_render(Config(primary_rays=1, **dict(kw, max_bounces=4)), sc, 3)
+        assert np.array_equal(c.view(np.uint32), d.view(np.uint32)) and sc_.bounces == sd.bounces
+
+
 def test_result_buffer_chunking(rtx_lib):
     """A result buffer smaller than the call's samples: the call is rendered in chunks."""
     sc = scenes.cornell()
