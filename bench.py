@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--pool", type=int, default=0, help="in-flight path pool (0 = library default)")
     ap.add_argument("--finish-paths", type=int, default=0, help="drain-kernel threshold (0 = library default)")
+    ap.add_argument("--primary-rays", type=int, default=0, choices=[0, 1],
+                    help="1 = primary rays always written by the generate kernel and read back (0 = library's choice)")
     ap.add_argument("--strong", action="store_true", help="split the workload's spp across ranks instead")
     ap.add_argument("--tiles", type=int, default=1,
                     help="row bands: ranks form TILES groups, group g renders band g of the frame and the "
@@ -148,7 +150,7 @@ def main():
     else:
         spp, base = spp_full, replica * spp_full
     cfg = Config(width=W, height=H, sky=wl["sky"], device=local_rank, pool_paths=args.pool,
-                 finish_paths=args.finish_paths)
+                 finish_paths=args.finish_paths, primary_rays=args.primary_rays)
     sc = wl["scene"]()
 
     r = Renderer(cfg)
