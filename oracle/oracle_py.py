@@ -114,6 +114,9 @@ def ref_pcg() -> Optional[C.CDLL]:
     L.ref_pcg_hash.argtypes = [C.c_uint32]
     L.ref_pcg_rand.argtypes = [C.POINTER(C.c_uint32), C.c_void_p, C.c_size_t]
     L.ref_pcg_uniform.argtypes = [C.POINTER(C.c_uint32), C.c_void_p, C.c_size_t]
+    if hasattr(L, "ref_eps"):
+        L.ref_eps.restype = C.c_float
+        L.ref_nee_emission_threshold.restype = C.c_float
     return L
 
 

@@ -12,6 +12,8 @@
  *     against the reference's own Sampler.h compiled unchanged into
  *     oracle/_ref/libref_pcg.so (see oracle/Makefile) and against the golden
  *     vectors generated from that build (tests/golden/pcg_kat.json).
+ *   - EPS and NEE_EMISSION_THRESHOLD: PINNED.  The reference's globals.h (macros only) is
+ *     compiled unchanged into the same library; tests/golden/pcg_kat.json records the values.
  *   - Oven-box radiance (closed room, emission 0.5, albedo 0.5 -> 1.0):
  *     PINNED to the analytic answer stated at Raytracer.cpp:203-214; the same room
  *     with a glass and a mirror sphere of albedo 1 inside keeps that answer and

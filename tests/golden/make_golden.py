@@ -41,6 +41,10 @@ def pcg():
         u, st2 = orc.pcg_uniform(seed, 64, ref)
         out["seeds"][str(seed)] = {"rand": [int(x) for x in r], "state_after": int(st),
                                    "uniform_bits": [int(x) for x in u.view(np.uint32)]}
+    out["constants"] = {"EPS_bits": int(np.float32(ref.ref_eps()).view(np.uint32)),
+                        "NEE_EMISSION_THRESHOLD_bits": int(np.float32(ref.ref_nee_emission_threshold()).view(np.uint32)),
+                        "WIDTH": int(ref.ref_width()), "HEIGHT": int(ref.ref_height()),
+                        "source": "reference globals.h:3-8 compiled unchanged"}
     out["hash"] = {str(x): int(ref.ref_pcg_hash(x)) for x in [0, 1, 2, 12345, 0xDEADBEEF, 0xFFFFFFFF]}
     with open(os.path.join(HERE, "pcg_kat.json"), "w") as f:
         json.dump(out, f, indent=1)

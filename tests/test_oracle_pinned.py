@@ -93,3 +93,16 @@ def test_oven_with_glass_and_mirror_is_still_one(oracle):
     img = img / spp
     assert abs(img.mean() - 1.0) < 0.01, img.mean()
     assert st.nee_samples == 0 and st.nan_paths == 0
+
+
+def test_constants_match_the_reference_header():
+    """EPS and NEE_EMISSION_THRESHOLD (reference globals.h:3-8, compiled unchanged into
+    oracle/_ref and recorded in the golden file) are the defaults of the configuration on both
+    sides; MAX_BOUNCE_PROB (Integrator.h:12) cannot be compiled here and is pinned by reading."""
+    with open(os.path.join(os.path.dirname(__file__), "golden", "pcg_kat.json")) as f:
+        k = json.load(f)["constants"]
+    cfg = Config()
+    assert int(np.float32(cfg.eps).view(np.uint32)) == k["EPS_bits"]
+    assert int(np.float32(cfg.nee_threshold).view(np.uint32)) == k["NEE_EMISSION_THRESHOLD_bits"]
+    assert (k["WIDTH"], k["HEIGHT"]) == (800, 800)
+    assert np.float32(cfg.rr_cap) == np.float32(0.99)
