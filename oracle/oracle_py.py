@@ -16,6 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librt_oracle.so")
 REF_PCG_PATH = os.path.join(_HERE, "_ref", "libref_pcg.so")
+REF_IO_PATH = os.path.join(_HERE, "_ref", "libref_io.so")
 
 
 class OMaterial(C.Structure):
@@ -118,6 +119,56 @@ def ref_pcg() -> Optional[C.CDLL]:
         L.ref_eps.restype = C.c_float
         L.ref_nee_emission_threshold.restype = C.c_float
     return L
+
+
+def ref_io() -> Optional[C.CDLL]:
+    """The reference's vendored OBJ reader and EXR writer compiled unchanged (None if never built)."""
+    if not os.path.exists(REF_IO_PATH):
+        return None
+    L = C.CDLL(REF_IO_PATH)
+    L.ref_obj_triangles.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_int)),
+                                    C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.ref_free.argtypes = [C.c_void_p]
+    L.ref_exr_save.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
+    L.ref_exr_load.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    return L
+
+
+def ref_obj_triangles(path: str):
+    """(triangles [n,3,3] float32, material id per triangle int32 (-1 = none), number of materials)
+    as the reference's loader sees the file: tinyobj::ObjReader with its default configuration and
+    the fan loop of Scene::load_mesh (reference Scene.h:55-115)."""
+    L = ref_io()
+    tris, mats = C.POINTER(C.c_float)(), C.POINTER(C.c_int)()
+    n, nm = C.c_size_t(), C.c_size_t()
+    rc = L.ref_obj_triangles(path.encode(), C.byref(tris), C.byref(mats), C.byref(n), C.byref(nm))
+    if rc != 0:
+        raise RuntimeError(f"reference OBJ reader failed ({rc}) on {path}")
+    t = np.ctypeslib.as_array(tris, (n.value, 3, 3)).copy() if n.value else np.zeros((0, 3, 3), np.float32)
+    m = np.ctypeslib.as_array(mats, (n.value,)).copy() if n.value else np.zeros((0,), np.int32)
+    L.ref_free(tris)
+    L.ref_free(mats)
+    return t, m, nm.value
+
+
+def ref_exr_save(rgb: np.ndarray, path: str) -> None:
+    """rgb [h,w,3] float32 through the call sequence of Img::saveEXR (reference Raytracer.cpp:83-143)."""
+    a = np.ascontiguousarray(rgb, np.float32)
+    rc = ref_io().ref_exr_save(_p(a), a.shape[1], a.shape[0], path.encode())
+    if rc != 0:
+        raise RuntimeError(f"reference EXR writer failed ({rc})")
+
+
+def ref_exr_load(path: str) -> np.ndarray:
+    """[h,w,4] float32 RGBA as tinyexr's LoadEXR reads the file."""
+    L = ref_io()
+    w, h = C.c_int(), C.c_int()
+    rc = L.ref_exr_load(path.encode(), None, 0, C.byref(w), C.byref(h))
+    out = np.zeros((h.value, w.value, 4), np.float32)
+    rc = L.ref_exr_load(path.encode(), _p(out), out.size, C.byref(w), C.byref(h))
+    if rc != 0:
+        raise RuntimeError(f"reference EXR reader failed ({rc})")
+    return out
 
 
 def _p(a):

@@ -21,11 +21,17 @@
  *   - Everything else (Vec3/Matrix3 arithmetic, camera, triangle/sphere
  *     intersection, castRay/isOccluded rules, light sampling, pathTrace):
  *     PARITY UNPINNED.  Vec3.h includes SFML and Scene.h/Obj.h include Embree 3;
- *     neither exists in this image and neither is vendored, so no other
- *     reference file can be compiled here without writing stand-ins for the
- *     missing headers.  The reference ships no tests, fixtures or golden data
- *     for this path.  These functions follow the reference source line by line
- *     (each cites the file:line it restates).
+ *     neither exists in this image and neither is vendored, so none of the
+ *     reference's own rendering files can be compiled here without writing
+ *     stand-ins for the missing headers.  The reference ships no tests, fixtures
+ *     or golden data for this path.  These functions follow the reference source
+ *     line by line (each cites the file:line it restates).
+ *   - Outside this library, the file formats either side of the loop: PINNED.  The
+ *     third-party sources the reference vendors and calls for them (tiny_obj_loader.h in
+ *     Scene::load_mesh, tinyexr.h + miniz in Img::saveEXR) are self-contained and compile
+ *     unchanged into oracle/_ref/libref_io.so (ref_io_wrap.cpp); tests/test_formats.py checks
+ *     the host layer's OBJ front end and EXR writer against it and against the fixtures
+ *     generated from it (tests/golden/formats).
  */
 #ifndef RT_ORACLE_H
 #define RT_ORACLE_H

@@ -40,6 +40,7 @@ int main(int argc, char** argv) {
   std::string obj, out = "render";
   uint32_t width = 800, height = 800, spp = 16, passes = 1;
   bool sky = false, parse_only = false;
+  std::string pfm_in, exr_out;
   for (int i = 1; i < argc; i++) {
     auto next = [&](const char* name) -> const char* {
       if (i + 1 >= argc) {
@@ -56,12 +57,23 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--out")) out = next("--out");
     else if (!std::strcmp(argv[i], "--sky")) sky = true;
     else if (!std::strcmp(argv[i], "--parse-only")) parse_only = true;
+    else if (!std::strcmp(argv[i], "--pfm-to-exr")) {
+      pfm_in = next("--pfm-to-exr");
+      exr_out = next("--pfm-to-exr");
+    }
     else {
       std::cerr << "unknown argument " << argv[i] << "\n";
       return 2;
     }
   }
   try {
+    if (!pfm_in.empty()) {
+      // Image writer only (no device needed): a float image in, the saveEXR file out.
+      Img img(1, 1);
+      if (!img.loadPFM(pfm_in.c_str())) throw Error("cannot read " + pfm_in);
+      if (!img.saveEXR(exr_out.c_str())) throw Error("cannot write " + exr_out);
+      return 0;
+    }
     if (parse_only) {
       // OBJ front end only (no device needed): prints what load_mesh produced.
       if (obj.empty()) throw Error("--parse-only needs --obj");
@@ -119,9 +131,10 @@ int main(int argc, char** argv) {
     check(rtx_get_stats(scene.ctx(), &st), "rtx_get_stats");
     std::printf("paths %llu, path-bounces %llu, shadow rays %llu\n", (unsigned long long)st.paths,
                 (unsigned long long)st.bounces, (unsigned long long)st.shadow_rays);
-    if (!img.savePFM((out + ".pfm").c_str()) || !img.savePPM((out + ".ppm").c_str()))
-      throw Error("cannot write " + out + ".pfm/.ppm");
-    std::printf("Saved %s.pfm and %s.ppm\n", out.c_str(), out.c_str());
+    if (!img.savePFM((out + ".pfm").c_str()) || !img.savePPM((out + ".ppm").c_str()) ||
+        !img.saveEXR((out + ".exr").c_str()))
+      throw Error("cannot write " + out + ".pfm/.ppm/.exr");
+    std::printf("Saved %s.pfm, %s.ppm and %s.exr\n", out.c_str(), out.c_str(), out.c_str());
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());
     return 1;

@@ -18,7 +18,10 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
+#include <iterator>
+#include <limits>
 #include <map>
 #include <sstream>
 #include <stdexcept>
@@ -110,99 +113,286 @@ inline rtx_config default_config(uint32_t width = 800, uint32_t height = 800) {
 }
 
 namespace detail {
-// Index of an OBJ "v" reference: 1-based, negative = relative to the end.
-inline bool obj_index(const std::string& tok, size_t nverts, size_t& out) {
-  long v = std::strtol(tok.c_str(), nullptr, 10);  // stops at '/', so v, v/vt, v//vn, v/vt/vn all work
-  if (v > 0 && (size_t)v <= nverts) {
-    out = (size_t)v - 1;
-    return true;
+inline bool blank(char c) { return c == ' ' || c == '\t'; }
+inline bool digit(char c) { return (unsigned)(c - '0') < 10u; }
+inline const char* skip_blanks(const char* p) { return p + std::strspn(p, " \t"); }
+
+// Lines of a text file; "\n", "\r\n" and a lone "\r" all end a line.
+inline bool read_lines(const std::string& path, std::vector<std::string>& lines) {
+  std::ifstream f(path, std::ios::binary);
+  if (!f) return false;
+  std::string text((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  size_t start = 0;
+  for (size_t i = 0; i < text.size(); i++) {
+    if (text[i] != '\n' && text[i] != '\r') continue;
+    lines.emplace_back(text, start, i - start);
+    if (text[i] == '\r' && i + 1 < text.size() && text[i + 1] == '\n') i++;
+    start = i + 1;
   }
-  if (v < 0 && (size_t)(-v) <= nverts) {
-    out = nverts - (size_t)(-v);
-    return true;
-  }
-  return false;
+  if (start < text.size()) lines.emplace_back(text, start, text.size() - start);
+  return true;
 }
-inline std::vector<std::string> mtl_names(const std::string& path) {
-  std::vector<std::string> names;
-  std::ifstream f(path);
-  std::string line;
-  while (std::getline(f, line)) {
-    std::istringstream ss(line);
-    std::string key, name;
-    if ((ss >> key >> name) && key == "newmtl") names.push_back(name);
+
+// Decimal text in [p, end) to double with the arithmetic of the OBJ library the reference
+// parses with (tinyobjloader 2.0's number reader, behind Scene::load_mesh, reference
+// Scene.h:57-62).  That reader is not correctly rounded: it sums the integer digits as
+// m*10+d, adds each fraction digit times a power of ten (a literal for the first seven
+// places, pow(10,-k) after), and applies a decimal exponent e as ldexp(m*5^e, e).  Doing
+// the same sums in the same order gives the same double, hence the same float vertex.
+// Text after the number is ignored; false when there is no number.
+inline bool obj_number(const char* p, const char* end, double& out) {
+  static const double place[8] = {1.0, 0.1, 0.01, 0.001, 0.0001, 0.00001, 0.000001, 0.0000001};
+  if (p >= end) return false;
+  int sign = 1, e10 = 0;
+  bool dot_first = false;
+  if (*p == '+' || *p == '-') {
+    sign = *p == '-' ? -1 : 1;
+    p++;
+    dot_first = p != end && *p == '.';
+  } else if (*p == '.') {
+    dot_first = true;
+  } else if (!digit(*p)) {
+    return false;
   }
-  return names;
+  double m = 0.0;
+  if (!dot_first) {
+    const char* first = p;
+    for (; p != end && digit(*p); p++) {
+      m *= 10;
+      m += (int)(*p - '0');
+    }
+    if (p == first) return false;
+  }
+  if (p != end && *p == '.') {
+    p++;
+    for (int k = 1; p != end && digit(*p); p++, k++) m += (int)(*p - '0') * (k < 8 ? place[k] : std::pow(10.0, -k));
+  }
+  if (p != end && (*p == 'e' || *p == 'E')) {
+    p++;
+    int esign = 1;
+    if (p != end && (*p == '+' || *p == '-')) {
+      esign = *p == '-' ? -1 : 1;
+      p++;
+    } else if (p == end || !digit(*p)) {
+      return false;
+    }
+    const char* first = p;
+    for (; p != end && digit(*p); p++) e10 = e10 * 10 + (int)(*p - '0');
+    if (p == first) return false;
+    e10 *= esign;
+  }
+  out = sign * (e10 ? std::ldexp(m * std::pow(5.0, e10), e10) : m);
+  return true;
+}
+// The next blank-separated number of a line as float; a missing or malformed one is 0, as in
+// that library.
+inline float obj_real(const char*& p) {
+  p = skip_blanks(p);
+  const char* end = p + std::strcspn(p, " \t\r");
+  double v = 0.0;
+  obj_number(p, end, v);
+  p = end;
+  return (float)v;
+}
+
+// "newmtl" entries of an MTL stream in the order the library numbers them: an entry is
+// stored when the next one starts (unless its name is empty) and once more at the end of
+// the file, whatever the name; the name is the rest of the line; the first slot of a name is
+// the one "usemtl" refers to.
+inline void mtl_slots(const std::vector<std::string>& lines, std::map<std::string, int>& slot_of, size_t& count) {
+  std::string name;
+  auto store = [&]() {
+    slot_of.insert(std::make_pair(name, (int)count));
+    count++;
+  };
+  for (std::string line : lines) {
+    line = line.substr(0, line.find_last_not_of(" \t") + 1);
+    const char* p = skip_blanks(line.c_str());
+    if (std::strncmp(p, "newmtl", 6) != 0 || !blank(p[6])) continue;
+    if (!name.empty()) store();
+    name = p + 7;
+  }
+  store();
+}
+
+struct ObjFace {
+  std::vector<int> v;  // zero-based vertex indices
+  int material;        // slot, or -1
+};
+
+// One polygon to triangles the way the library does before load_mesh sees it (its default
+// configuration triangulates): ear clipping in the plane of the two axes along which the
+// polygon's first non-degenerate corner is widest.  Starting at vertex 0, the corner
+// (g, g+1, g+2) is cut off when it turns the way the polygon's signed area does and none of
+// the other vertices lies inside it; otherwise g moves on.  A convex polygon therefore
+// comes out as the fan (0,1,2), (0,2,3), ...; a polygon on which no ear is found in a full
+// round keeps only the triangles cut so far.
+inline void obj_triangulate(const std::vector<int>& face, const std::vector<float>& xyz, std::vector<int>& out) {
+  const size_t n = face.size(), nfloats = xyz.size();
+  auto coord = [&](int vi, size_t axis) { return xyz[(size_t)vi * 3 + axis]; };
+  size_t ax0 = 1, ax1 = 2;
+  for (size_t k = 0; k < n; k++) {
+    const int i0 = face[k], i1 = face[(k + 1) % n], i2 = face[(k + 2) % n];
+    const float e0x = coord(i1, 0) - coord(i0, 0), e0y = coord(i1, 1) - coord(i0, 1), e0z = coord(i1, 2) - coord(i0, 2);
+    const float e1x = coord(i2, 0) - coord(i1, 0), e1y = coord(i2, 1) - coord(i1, 1), e1z = coord(i2, 2) - coord(i1, 2);
+    const float cx = std::fabs(e0y * e1z - e0z * e1y);
+    const float cy = std::fabs(e0z * e1x - e0x * e1z);
+    const float cz = std::fabs(e0x * e1y - e0y * e1x);
+    const float tiny = std::numeric_limits<float>::epsilon();
+    if (cx > tiny || cy > tiny || cz > tiny) {
+      if (!(cx > cy && cx > cz)) {
+        ax0 = 0;
+        if (cz > cx && cz > cy) ax1 = 1;
+      }
+      break;
+    }
+  }
+  float area = 0;
+  for (size_t k = 0; k < n; k++) {
+    const int i0 = face[k], i1 = face[(k + 1) % n];
+    area += (coord(i0, ax0) * coord(i1, ax1) - coord(i0, ax1) * coord(i1, ax0)) * 0.5f;
+  }
+  (void)nfloats;
+  std::vector<int> rest = face;
+  size_t g = 0, tries = n, last_size = n;
+  while (rest.size() > 3 && tries > 0) {
+    const size_t m = rest.size();
+    if (g >= m) g -= m;
+    if (last_size != m) {
+      last_size = m;
+      tries = m;
+    } else {
+      tries--;
+    }
+    int ind[3];
+    float px[3], py[3];
+    for (size_t k = 0; k < 3; k++) {
+      ind[k] = rest[(g + k) % m];
+      px[k] = coord(ind[k], ax0);
+      py[k] = coord(ind[k], ax1);
+    }
+    const float cross = (px[1] - px[0]) * (py[2] - py[1]) - (py[1] - py[0]) * (px[2] - px[1]);
+    if (cross * area < 0.0f) {
+      g++;
+      continue;
+    }
+    bool inside = false;
+    for (size_t other = 3; other < m && !inside; other++) {
+      const int vi = rest[(g + other) % m];
+      const float tx = coord(vi, ax0), ty = coord(vi, ax1);
+      // crossing-number test of (tx,ty) against the triangle's three edges
+      for (int i = 0, j = 2; i < 3; j = i++)
+        if (((py[i] > ty) != (py[j] > ty)) && (tx < (px[j] - px[i]) * (ty - py[i]) / (py[j] - py[i]) + px[i]))
+          inside = !inside;
+    }
+    if (inside) {
+      g++;
+      continue;
+    }
+    out.insert(out.end(), ind, ind + 3);
+    rest.erase(rest.begin() + (ptrdiff_t)((g + 1) % m));
+  }
+  if (rest.size() == 3) out.insert(out.end(), rest.begin(), rest.end());
 }
 }  // namespace detail
 
-// The OBJ front end of Scene::load_mesh (Scene.h:55-115): reads a Wavefront OBJ; one Material per material of
-// its MTL library, initialised to the reference's placeholder (0.65,0.05,0.05) diffuse
-// (Scene.h:78) for the caller to override by slot; every face is fan-tessellated around
-// its first vertex (Scene.h:88-109).  Faces without a material (the reference would index
-// with -1 cast to unsigned, Scene.h:107) get one extra placeholder slot at the end.
+// The OBJ front end of Scene::load_mesh (Scene.h:55-115), which reads the file with
+// tinyobjloader in its default configuration and walks the result.  Same rules here:
+//  - "v x y z": numbers as detail::obj_number reads them, missing ones 0;
+//  - "f": vertex references v, v/vt, v//vn, v/vt/vn, 1-based or negative = relative to the
+//    vertices read so far; 0 or text is an error; faces of fewer than 3 vertices are dropped;
+//    larger ones go through detail::obj_triangulate, and load_mesh's fan over the resulting
+//    triangles (Scene.h:88-109) changes nothing;
+//  - "mtllib a b ...": the first of the names that opens (next to the OBJ file) is read;
+//    one Material per entry (detail::mtl_slots), initialised to the reference's placeholder
+//    (0.65,0.05,0.05) diffuse (Scene.h:78) for the caller to override by slot;
+//  - "usemtl name": the slot for the faces that follow, none for an unknown name.
+// Two deliberate differences: faces without a material (the reference would index its
+// material list with -1, Scene.h:107) get one extra placeholder slot at the end, and a face
+// that refers to a vertex the file never defines is an error instead of a read outside the
+// vertex array.  Polygons are triangulated once the whole file is read, so a face may refer
+// to a vertex defined further down.
 inline Mesh* load_obj(const std::string& file_name) {
-  std::ifstream f(file_name);
-  if (!f) throw Error("load_mesh: cannot open " + file_name);
-  Mesh* mesh = new Mesh();
-  std::vector<Vec3> verts;
-  std::map<std::string, unsigned> slot_of;
-  std::string dir = file_name.substr(0, file_name.find_last_of("/\\") + 1);
-  const Material placeholder{Vec3(0.65f, 0.05f, 0.05f), 0.0f, diffuse};
+  std::vector<std::string> lines;
+  if (!detail::read_lines(file_name, lines)) throw Error("load_mesh: cannot open " + file_name);
+  const std::string dir = file_name.substr(0, file_name.find_last_of("/\\") + 1);
+  std::vector<float> xyz;
+  std::vector<detail::ObjFace> faces;
+  std::map<std::string, int> slot_of;
+  size_t num_materials = 0;
   int current = -1;
-  bool need_default = false;
-  std::vector<std::pair<size_t, int>> tri_slots;  // (triangle, material slot or -1)
-  std::string line;
-  size_t lineno = 0;
-  while (std::getline(f, line)) {
-    lineno++;
-    std::istringstream ss(line);
-    std::string key;
-    if (!(ss >> key) || key[0] == '#') continue;
-    if (key == "v") {
-      Vec3 v;
-      if (!(ss >> v.x >> v.y >> v.z)) {
-        delete mesh;
-        throw Error("load_mesh: bad vertex at line " + std::to_string(lineno));
-      }
-      verts.push_back(v);
-    } else if (key == "mtllib") {
-      std::string name;
-      ss >> name;
-      for (const std::string& n : detail::mtl_names(dir + name))
-        if (!slot_of.count(n)) {
-          slot_of[n] = (unsigned)mesh->materials.size();
-          mesh->add_material(placeholder);
+  for (size_t lineno = 1; lineno <= lines.size(); lineno++) {
+    const char* p = detail::skip_blanks(lines[lineno - 1].c_str());
+    if (p[0] == '\0' || p[0] == '#') continue;
+    if (p[0] == 'v' && detail::blank(p[1])) {
+      p += 2;
+      for (int c = 0; c < 3; c++) xyz.push_back(detail::obj_real(p));
+    } else if (p[0] == 'f' && detail::blank(p[1])) {
+      p = detail::skip_blanks(p + 2);
+      detail::ObjFace face;
+      face.material = current;
+      while (*p != '\0' && *p != '\r' && *p != '\n') {
+        // v, v/vt, v//vn or v/vt/vn; every index that is present must be a non-zero number
+        const int raw = std::atoi(p);
+        bool ok = raw != 0;
+        p += std::strcspn(p, "/ \t\r");
+        for (int part = 0; ok && part < 2 && *p == '/'; part++) {
+          p++;
+          if (part == 0 && *p == '/') continue;  // no texture index
+          ok = std::atoi(p) != 0;
+          p += std::strcspn(p, "/ \t\r");
         }
-    } else if (key == "usemtl") {
-      std::string name;
-      ss >> name;
-      auto it = slot_of.find(name);
-      current = it == slot_of.end() ? -1 : (int)it->second;
-    } else if (key == "f") {
-      std::vector<size_t> idx;
-      std::string tok;
-      while (ss >> tok) {
-        size_t i;
-        if (!detail::obj_index(tok, verts.size(), i)) {
-          delete mesh;
-          throw Error("load_mesh: bad face index at line " + std::to_string(lineno));
-        }
-        idx.push_back(i);
+        if (!ok) throw Error("load_mesh: bad face index at line " + std::to_string(lineno));
+        face.v.push_back(raw > 0 ? raw - 1 : (int)(xyz.size() / 3) + raw);
+        p += std::strspn(p, " \t\r");
       }
-      for (size_t v = 2; v < idx.size(); v++) {  // fan around the first vertex, b = previous c
-        tri_slots.emplace_back(mesh->triangles.size(), current);
-        mesh->add_triangle(Triangle{verts[idx[0]], verts[idx[v - 1]], verts[idx[v]]}, 0);
-        if (current < 0) need_default = true;
+      faces.push_back(std::move(face));
+    } else if (!std::strncmp(p, "usemtl", 6)) {
+      p = detail::skip_blanks(p + 6);
+      auto it = slot_of.find(std::string(p, std::strcspn(p, " \t\r")));
+      current = it == slot_of.end() ? -1 : it->second;
+    } else if (!std::strncmp(p, "mtllib", 6) && detail::blank(p[6])) {
+      // names separated by single spaces, a backslash keeps the next character
+      std::vector<std::string> names(1);
+      for (p += 7; *p; p++) {
+        if (*p == '\\' && p[1]) names.back() += *++p;
+        else if (*p == '\\') break;
+        else if (*p == ' ') {
+          if (names.back().empty()) continue;
+          names.emplace_back();
+        } else names.back() += *p;
+      }
+      for (const std::string& name : names) {
+        std::vector<std::string> mtl;
+        if (!detail::read_lines(dir + name, mtl)) continue;
+        detail::mtl_slots(mtl, slot_of, num_materials);
+        break;
       }
     }
   }
-  unsigned default_slot = 0;
-  if (need_default) {
-    default_slot = (unsigned)mesh->materials.size();
-    mesh->add_material(placeholder);
+  Mesh* mesh = new Mesh();
+  const Material placeholder{Vec3(0.65f, 0.05f, 0.05f), 0.0f, diffuse};
+  for (size_t i = 0; i < num_materials; i++) mesh->add_material(placeholder);
+  bool need_default = false;
+  std::vector<int> tri;
+  const int nverts = (int)(xyz.size() / 3);
+  for (const detail::ObjFace& face : faces) {
+    if (face.v.size() < 3) continue;
+    for (int vi : face.v)
+      if (vi < 0 || vi >= nverts) {
+        delete mesh;
+        throw Error("load_mesh: bad face index (vertex " + std::to_string(vi + 1) + " is not in the file)");
+      }
+    tri.clear();
+    detail::obj_triangulate(face.v, xyz, tri);
+    auto vertex = [&](int vi) { return Vec3(xyz[3 * (size_t)vi], xyz[3 * (size_t)vi + 1], xyz[3 * (size_t)vi + 2]); };
+    for (size_t t = 0; t + 2 < tri.size(); t += 3) {
+      mesh->add_triangle(Triangle{vertex(tri[t]), vertex(tri[t + 1]), vertex(tri[t + 2])},
+                         face.material < 0 ? (unsigned)num_materials : (unsigned)face.material);
+      if (face.material < 0) need_default = true;
+    }
   }
-  for (auto& ts : tri_slots) mesh->material_idxs[ts.first] = ts.second < 0 ? default_slot : (unsigned)ts.second;
+  if (need_default) mesh->add_material(placeholder);
   return mesh;
 }
 
@@ -292,6 +482,117 @@ class Img {
     std::fprintf(f, "PF\n%u %u\n-1.0\n", width, height);
     for (uint32_t y = height; y-- > 0;) std::fwrite(&pixels[(size_t)y * width], sizeof(Vec3), width, f);
     return std::fclose(f) == 0;
+  }
+  // OpenEXR file as Img::saveEXR writes it through tinyexr (reference Raytracer.cpp:83-143):
+  // one scanline part, no compression (InitEXRHeader leaves the type at 0), three HALF
+  // channels named B, G, R, data and display window the whole image, one chunk per line
+  // holding the line's B values, then G, then R.  Written here directly; the bytes are the
+  // ones tinyexr produces (checked against the reference's vendored copy in the tests).
+  // Float to half as tinyexr converts: the mantissa is cut to ten bits and rounded up when
+  // the first dropped bit is set; below the half range the value is shifted into a
+  // denormal the same way, float denormals become signed zero, overflow becomes infinity.
+  static uint16_t half_bits(float v) {
+    uint32_t u;
+    std::memcpy(&u, &v, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u, exp = (u >> 23) & 0xffu, man = u & 0x7fffffu;
+    uint32_t h = 0;
+    if (exp == 0) {
+      h = 0;
+    } else if (exp == 255) {
+      h = 0x7c00u | (man ? 0x200u : 0u);
+    } else {
+      const int e = (int)exp - 127 + 15;
+      if (e >= 31) {
+        h = 0x7c00u;
+      } else if (e <= 0) {
+        if (14 - e <= 24) {
+          const uint32_t m = man | 0x800000u;
+          h = m >> (14 - e);
+          if ((m >> (13 - e)) & 1u) h++;
+        }
+      } else {
+        h = ((uint32_t)e << 10) | (man >> 13);
+        if (man & 0x1000u) h++;
+      }
+    }
+    return (uint16_t)(sign | h);
+  }
+  bool saveEXR(const char* path) const {
+    std::vector<unsigned char> out;
+    auto put = [&](const void* p, size_t n) {
+      const unsigned char* b = static_cast<const unsigned char*>(p);
+      out.insert(out.end(), b, b + n);
+    };
+    auto put_u32 = [&](uint32_t v) { put(&v, 4); };  // the file is little endian, as is the host
+    auto attribute = [&](const char* name, const char* type, const void* data, uint32_t n) {
+      put(name, std::strlen(name) + 1);
+      put(type, std::strlen(type) + 1);
+      put_u32(n);
+      put(data, n);
+    };
+    const unsigned char magic_version[8] = {0x76, 0x2f, 0x31, 0x01, 2, 0, 0, 0};
+    put(magic_version, 8);
+    {
+      std::vector<unsigned char> ch;
+      for (const char* name : {"B", "G", "R"}) {
+        ch.push_back((unsigned char)name[0]);
+        ch.push_back(0);
+        const uint32_t fields[4] = {1u /* HALF */, 0u /* pLinear + 3 reserved */, 1u, 1u /* sampling */};
+        const unsigned char* b = reinterpret_cast<const unsigned char*>(fields);
+        ch.insert(ch.end(), b, b + 16);
+      }
+      ch.push_back(0);
+      attribute("channels", "chlist", ch.data(), (uint32_t)ch.size());
+    }
+    const unsigned char none = 0;
+    attribute("compression", "compression", &none, 1);
+    const int32_t window[4] = {0, 0, (int32_t)width - 1, (int32_t)height - 1};
+    attribute("dataWindow", "box2i", window, 16);
+    attribute("displayWindow", "box2i", window, 16);
+    attribute("lineOrder", "lineOrder", &none, 1);  // increasing y
+    const float one = 1.0f, centre[2] = {0.0f, 0.0f};
+    attribute("pixelAspectRatio", "float", &one, 4);
+    attribute("screenWindowCenter", "v2f", centre, 8);
+    attribute("screenWindowWidth", "float", &one, 4);
+    out.push_back(0);  // end of header
+    const uint64_t line_bytes = 8 + (uint64_t)width * 6;
+    uint64_t offset = out.size() + (uint64_t)height * 8;
+    for (uint32_t y = 0; y < height; y++, offset += line_bytes) put(&offset, 8);
+    std::vector<uint16_t> line((size_t)width * 3);
+    for (uint32_t y = 0; y < height; y++) {
+      put_u32(y);
+      put_u32(width * 6u);
+      const Vec3* row = &pixels[(size_t)y * width];
+      for (uint32_t x = 0; x < width; x++) {
+        line[x] = half_bits(row[x].z);
+        line[width + x] = half_bits(row[x].y);
+        line[2 * (size_t)width + x] = half_bits(row[x].x);
+      }
+      put(line.data(), line.size() * 2);
+    }
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return false;
+    const bool ok = std::fwrite(out.data(), 1, out.size(), f) == out.size();
+    return (std::fclose(f) == 0) && ok;
+  }
+  // Reads what savePFM wrote (or any little-endian RGB PFM) back into pixels.
+  bool loadPFM(const char* path) {
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return false;
+    unsigned w = 0, h = 0;
+    float scale = 0;
+    char tag[3] = {0, 0, 0};
+    bool ok = std::fscanf(f, "%2s %u %u %f", tag, &w, &h, &scale) == 4 && !std::strcmp(tag, "PF") && scale < 0 &&
+              std::fgetc(f) == '\n';
+    if (ok) {
+      width = w;
+      height = h;
+      pixels.assign((size_t)w * h, Vec3());
+      for (uint32_t y = height; ok && y-- > 0;)
+        ok = std::fread(&pixels[(size_t)y * width], sizeof(Vec3), width, f) == width;
+    }
+    std::fclose(f);
+    return ok;
   }
   // 8-bit sRGB with the reference's transfer function (Vec3.cpp:39-53): clamp to 1, then
   // 12.92x below 0.0031308, 1.055 x^(1/2.4) - 0.055 above.

@@ -12,6 +12,12 @@ functions.npz       camera rays on a 64x64 grid (800^2 and 1024^2, three cameras
                     oracle.  Regression vectors of the restatement: parity unpinned.
 image_*.npz         128x128 images of the oracle at IMAGE_SPP samples per pixel (sums / spp),
                     seed 0x5EED, with the bounce count.  Regression vectors as well.
+formats/shapes.npz  what the REFERENCE's vendored OBJ reader (tiny_obj_loader.h behind Scene::load_mesh's
+                    loop, compiled unchanged into oracle/_ref/libref_io.so) makes of formats/shapes.obj
+                    + shapes.mtl (hand-written for this test): triangles, material ids, material count.
+formats/image.npz   a small float image with ordinary and special values, and formats/image.exr, the
+                    file the REFERENCE's writer (tinyexr.h through the call sequence of Img::saveEXR)
+                    makes of it.  Both pin the host layer's file formats to the reference.
 closest_*.npz       fixed ray sets with (kind, prim, t) from the oracle's first-party
                     linear scan.  These are regression vectors of the restatement, not
                     outputs of the reference (which cannot be built here): parity unpinned.
@@ -127,7 +133,31 @@ def images():
                             spp=IMAGE_SPP, sky=sky, bounces=st.bounces, nee_samples=st.nee_samples)
 
 
+def exr_test_image():
+    """13x7 image: smooth ramp, random magnitudes across the half range and beyond, and special values."""
+    rng = np.random.default_rng(77)
+    h, w = 7, 13
+    img = (rng.standard_normal((h, w, 3)) * np.exp(rng.uniform(-22, 13, (h, w, 3)))).astype(np.float32)
+    img[0] = np.linspace(0, 4, w * 3, dtype=np.float32).reshape(w, 3)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 65504.0, 65520.0, 65519.996, 6.1e-5, 5.96e-8, 2.98e-8,
+                        2.9e-8, 1e-45, 1.0009766, 1.0004883, 1.0014648, 0.33333334, 2049.0, 2051.0], np.float32)
+    img[1].reshape(-1)[:special.size] = special
+    return img
+
+
+def formats():
+    if orc.ref_io() is None:
+        raise SystemExit("oracle/_ref/libref_io.so missing: run `make -C oracle` where /root/reference exists")
+    d = os.path.join(HERE, "formats")
+    tris, mats, nmat = orc.ref_obj_triangles(os.path.join(d, "shapes.obj"))
+    np.savez_compressed(os.path.join(d, "shapes.npz"), triangles=tris, material_ids=mats, num_materials=nmat)
+    img = exr_test_image()
+    np.savez_compressed(os.path.join(d, "image.npz"), rgb=img)
+    orc.ref_exr_save(img, os.path.join(d, "image.exr"))
+
+
 if __name__ == "__main__":
+    formats()
     pcg()
     closest()
     functions()

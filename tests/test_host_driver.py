@@ -1,6 +1,7 @@
 """The C++ host layer (raytracer_amd/host): the Raytracer.cpp-shaped driver above the C ABI.
 CPU: it builds with plain g++ and its OBJ front end reproduces Scene::load_mesh's rules
-(fan tessellation around the first vertex, one material slot per MTL material, Scene.h:55-115).
+(convex faces come out as a fan around the first vertex, one material slot per MTL material,
+Scene.h:55-115; tests/test_formats.py holds the comparison with the reference's own loader).
 GPU: a progressive render through the driver equals the same render through the Python binding."""
 import os
 import subprocess
