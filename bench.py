@@ -37,6 +37,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 BYTES = {
     "intersect": 24 + 8,                  # ray read + hit record written
     "shade": 52 + 8 + 52 + 4 + 4 + 12,    # state read, hit read, state written, compaction index r/w, radiance RMW
+    "trace_shade": 52 + 52 + 4 + 4 + 12,  # search and shading in one kernel: no ray or hit record in between
     "shadow": 44 + 44,                    # shadow record written by shade and read by shadow
     "generate": 52,                       # state written per primary sample
 }
@@ -50,6 +51,8 @@ def workloads():
         "sample3_mis_cornell": dict(scene=lambda: scenes.cornell(), sky=0, width=1024, height=1024, spp=256),
         "sample3_mis_cornell_4lights": dict(scene=lambda: scenes.cornell(lights=4), sky=0, width=1024, height=1024, spp=256),
         "mesh_1m": dict(scene=lambda: scenes.terrain(707), sky=0, width=1920, height=1080, spp=256),
+        "soup150": dict(scene=lambda: scenes.soup(150, 3, seed=2), sky=1, width=1024, height=1024, spp=64),
+        "soup3k": dict(scene=lambda: scenes.soup(3000, 3, seed=2), sky=1, width=1024, height=1024, spp=64),
         "mis_4k": dict(scene=lambda: scenes.cornell(), sky=0, width=3840, height=2160, spp=4096),
     }
 
@@ -101,6 +104,8 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--pool", type=int, default=0, help="in-flight path pool (0 = library default)")
     ap.add_argument("--finish-paths", type=int, default=0, help="drain-kernel threshold (0 = library default)")
+    ap.add_argument("--fused-trace", type=int, default=0, choices=[0, 1, 2],
+                    help="rtx_config.fused_trace: 0 library chooses, 1 search and shading in two kernels, 2 in one")
     ap.add_argument("--primary-rays", type=int, default=0, choices=[0, 1],
                     help="1 = primary rays always written by the generate kernel and read back (0 = library's choice)")
     ap.add_argument("--strong", action="store_true", help="split the workload's spp across ranks instead")
@@ -150,7 +155,7 @@ def main():
     else:
         spp, base = spp_full, replica * spp_full
     cfg = Config(width=W, height=H, sky=wl["sky"], device=local_rank, pool_paths=args.pool,
-                 finish_paths=args.finish_paths, primary_rays=args.primary_rays)
+                 finish_paths=args.finish_paths, primary_rays=args.primary_rays, fused_trace=args.fused_trace)
     sc = wl["scene"]()
 
     r = Renderer(cfg)
@@ -238,6 +243,9 @@ def main():
         extra_ms = {"finish": p.ms_finish, "reduce": p.ms_reduce}
         dom = max(stage, key=lambda k: stage[k][0])
         ms, launches, units = stage[dom]
+        fused = p.timed_launches_intersect == 0      # k_trace_shade is timed as the shade stage
+        if dom == "shade" and fused:
+            dom = "trace_shade"
         if launches and ms > 0:
             bytes_per_launch = BYTES[dom] * units / launches
             avg_ms = ms / launches
@@ -252,7 +260,8 @@ def main():
         dist.barrier()
 
     if rank == 0:
-        pipeline_bytes = 164 * bounces + 88 * shadows + 52 * paths
+        fused_run = bool(stage) and stage["intersect"][1] == 0
+        pipeline_bytes = (124 if fused_run else 164) * bounces + 88 * shadows + 52 * paths
         out = {
             "metric": "Mpath-bounces/sec & time-to-image (1024², 256 spp) at 1/2/4/8 GPUs",
             "value": round(bounces / elapsed / 1e6, 2),

@@ -107,6 +107,10 @@ typedef struct {
                             (recomputed from the sample number by each kernel that needs them where that
                             is cheaper than a round trip through memory), 1 = always written by the
                             generate kernel and read back.  Both give the same bits. */
+  int32_t fused_trace;   /* closest-hit search and shading of a bounce: 0 = the library chooses (one kernel
+                            where the tree is small enough to be staged in LDS: the search then costs less
+                            than passing the ray and the hit through memory; two kernels otherwise),
+                            1 = always two kernels, 2 = as 0 today.  All give the same bits. */
 } rtx_config;
 
 /* Scene geometry, borrowed for the duration of rtx_set_scene.

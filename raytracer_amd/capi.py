@@ -51,7 +51,7 @@ class CConfig(C.Structure):
         ("focal_length", C.c_float), ("lens_radius", C.c_float),
         ("stretch_x", C.c_float), ("stretch_y", C.c_float),
         ("device", C.c_int32), ("pool_paths", C.c_uint32),
-        ("finish_paths", C.c_uint32), ("result_buffer_mib", C.c_uint32), ("primary_rays", C.c_int32),
+        ("finish_paths", C.c_uint32), ("result_buffer_mib", C.c_uint32), ("primary_rays", C.c_int32), ("fused_trace", C.c_int32),
     ]
 
 
@@ -157,6 +157,7 @@ class Config:
     finish_paths: int = 0
     result_buffer_mib: int = 0
     primary_rays: int = 0
+    fused_trace: int = 0
 
     def to_c(self) -> CConfig:
         c = CConfig()
@@ -169,6 +170,7 @@ class Config:
         c.device, c.pool_paths = self.device, self.pool_paths
         c.finish_paths, c.result_buffer_mib = self.finish_paths, self.result_buffer_mib
         c.primary_rays = self.primary_rays
+        c.fused_trace = self.fused_trace
         return c
 
 

@@ -1401,6 +1401,44 @@ __global__ __launch_bounds__(BLOCK, 7) void k_intersect_wide(SceneDev sc, Queue 
   }
 }
 
+// Block-level append: one atomic per block reserves the slots of all its waves, so the
+// survivors of a block land in one run (fewer runs, fewer shared lines).  Every thread of
+// the block must call it (two barriers).  Same outputs as wave_append.
+__device__ __forceinline__ void block_append(bool alive, bool want_shadow, bool did_nee, unsigned long long* counter,
+                                             uint32_t& pos, uint32_t& spos) {
+  __shared__ uint32_t wave_counts[16][3];
+  __shared__ unsigned long long block_old;
+  const unsigned long long mp = __ballot(alive), ms = __ballot(want_shadow), mn = __ballot(did_nee);
+  const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  if (lane == 0) {
+    wave_counts[w][0] = (uint32_t)__popcll(mp);
+    wave_counts[w][1] = (uint32_t)__popcll(ms);
+    wave_counts[w][2] = (uint32_t)__popcll(mn);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t a = 0, b = 0, c = 0;
+    for (uint32_t k = 0; k < (blockDim.x >> 6); k++) {
+      a += wave_counts[k][0];
+      b += wave_counts[k][1];
+      c += wave_counts[k][2];
+    }
+    const unsigned long long add = (unsigned long long)a | ((unsigned long long)b << kPathBits) |
+                                   ((unsigned long long)c << (kPathBits + kShadowBits));
+    block_old = add ? atomicAdd(counter, add) : 0ull;
+  }
+  __syncthreads();
+  const unsigned long long old = block_old;
+  pos = seg_paths(old);
+  spos = seg_shadow(old);
+  for (uint32_t k = 0; k < w; k++) {
+    pos += wave_counts[k][0];
+    spos += wave_counts[k][1];
+  }
+  pos += __builtin_amdgcn_mbcnt_hi((uint32_t)(mp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mp, 0u));
+  spos += __builtin_amdgcn_mbcnt_hi((uint32_t)(ms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ms, 0u));
+}
+
 // One bounce for every path of queue `qi`; survivors are appended to the same
 // segment of `out`, finished paths store their colour to their sample's slot.
 __global__ __launch_bounds__(256) void k_shade_wave_append(SceneDev sc, Queue in, Queue out, ShadowQueue sq,
@@ -1434,14 +1472,51 @@ __global__ __launch_bounds__(256) void k_shade_wave_append(SceneDev sc, Queue in
   }
 }
 
+// k_intersect and k_shade_wave_append in one launch, for scenes whose closest-hit search is
+// a handful of tests (tree staged in LDS, a few nodes): the search then costs less than
+// carrying the ray to a kernel of its own and the hit back, so each path is read once per
+// bounce and the hit stays in registers.
+template <int BLOCK, int MODE>
+__global__ __launch_bounds__(BLOCK) void k_trace_shade(SceneDev sc, Queue in, Queue out, ShadowQueue sq,
+                                                       SegCounter* seg, int qi, uint32_t cap, float* res,
+                                                       TraceParams tp, const Primary* __restrict__ prp) {
+  const uint32_t s = blockIdx.y;
+  const uint32_t n = seg_paths(seg[s].c[qi]);
+  if (blockIdx.x * BLOCK >= n) return;  // whole blocks beyond the fill leave; the rest stay for the barrier and the ballots
+  RTX_TRACE_PROLOGUE();
+  const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+  const bool active = j < n;
+  const uint32_t i = s * cap + j;
+  const bool use_depth = sc.max_bounces != 0;
+
+  PathState p;
+  ShadowReq sr;
+  bool alive = false, want_shadow = false, did_nee = false;
+  if (active) {
+    load_path(in, i, use_depth, j >= seg[s].gen_slot0, *prp, (uint32_t)seg[s].gen_ordinal0 + (j - seg[s].gen_slot0), p);
+    float t;
+    uint32_t id;
+    cast_ray<MODE>(sc, geom, p.o, p.d, stk, t, id);
+    alive = shade_bounce(sc, global_geom(sc), p, t, id, want_shadow, did_nee, sr);
+    if (!alive) store_result(res, p.ordinal, p.col);
+  }
+  uint32_t pos, spos;  // (the per-block append of k_shade_block_append measured slower here)
+  wave_append(alive, want_shadow, did_nee, &seg[s].c[qi ^ 1], pos, spos);
+  if (alive) store_path(out, s * cap + pos, use_depth, p);
+  if (want_shadow) {
+    const uint32_t k = s * cap + spos;
+    sq.q0[k] = make_float4(p.o.x, p.o.y, p.o.z, sr.tfar);
+    sq.q1[k] = make_float4(sr.d.x, sr.d.y, sr.d.z, __uint_as_float(s * cap + pos));
+    sq.q2[k] = make_float4(sr.contrib.x, sr.contrib.y, sr.contrib.z, 0.0f);
+  }
+}
+
 // The same with one atomic per block.  Measured on MI355X: 7 % faster where most paths
 // go on and light samples are queued as well (closed room with lights: two appended
 // streams, long runs), 2 % slower where most paths end at once (open scene, sky).
 __global__ __launch_bounds__(256) void k_shade_block_append(SceneDev sc, Queue in, Queue out, ShadowQueue sq,
                                                             const uint2* hits, SegCounter* seg, int qi,
                                                             uint32_t cap, float* res, const Primary* __restrict__ prp) {
-  __shared__ uint32_t wave_counts[4][3];
-  __shared__ unsigned long long block_old;
   const uint32_t s = blockIdx.y;
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n = seg_paths(seg[s].c[qi]);
@@ -1459,36 +1534,8 @@ __global__ __launch_bounds__(256) void k_shade_block_append(SceneDev sc, Queue i
     alive = shade_bounce(sc, global_geom(sc), p, __uint_as_float(h.x), h.y, want_shadow, did_nee, sr);
     if (!alive) store_result(res, p.ordinal, p.col);
   }
-  // Block-level append: one atomic per block reserves the slots of its four waves,
-  // so the survivors of a block land in one run (fewer runs, fewer shared lines).
-  const unsigned long long mp = __ballot(alive), ms = __ballot(want_shadow), mn = __ballot(did_nee);
-  const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
-  if (lane == 0) {
-    wave_counts[w][0] = (uint32_t)__popcll(mp);
-    wave_counts[w][1] = (uint32_t)__popcll(ms);
-    wave_counts[w][2] = (uint32_t)__popcll(mn);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t a = 0, b = 0, c = 0;
-    for (uint32_t k = 0; k < (blockDim.x >> 6); k++) {
-      a += wave_counts[k][0];
-      b += wave_counts[k][1];
-      c += wave_counts[k][2];
-    }
-    const unsigned long long add = (unsigned long long)a | ((unsigned long long)b << kPathBits) |
-                                   ((unsigned long long)c << (kPathBits + kShadowBits));
-    block_old = add ? atomicAdd(&seg[s].c[qi ^ 1], add) : 0ull;
-  }
-  __syncthreads();
-  const unsigned long long old = block_old;
-  uint32_t pos = seg_paths(old), spos = seg_shadow(old);
-  for (uint32_t k = 0; k < w; k++) {
-    pos += wave_counts[k][0];
-    spos += wave_counts[k][1];
-  }
-  pos += __builtin_amdgcn_mbcnt_hi((uint32_t)(mp >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mp, 0u));
-  spos += __builtin_amdgcn_mbcnt_hi((uint32_t)(ms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ms, 0u));
+  uint32_t pos, spos;
+  block_append(alive, want_shadow, did_nee, &seg[s].c[qi ^ 1], pos, spos);
   if (alive) store_path(out, s * cap + pos, use_depth, p);
   if (want_shadow) {
     const uint32_t k = s * cap + spos;

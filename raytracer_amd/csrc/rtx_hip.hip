@@ -48,6 +48,7 @@ constexpr int kTraceBlock = 128;                 // threads per block of the tra
 constexpr size_t kLdsSceneMaxBytes = 16 * 1024;  // stage BVH + triangles in LDS up to this size
 constexpr int kWideLdsStack = 16;                // LDS stack entries per lane for the four-child tree
 constexpr int kFinishBlock = 64;
+constexpr size_t kFusedSmallSceneBytes = 4096;  // k_trace_shade: scenes up to this size run 128-thread blocks
 constexpr uint32_t kTraceBatches = 2;  // ray batches per block of k_intersect/k_shadow (the next batch's loads overlap the current traversal)
 constexpr int kPollSlots = 4;
 
@@ -188,6 +189,8 @@ int rtx_create(const rtx_config* cfg, rtx_ctx** out) {
     return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_create: bad camera or integrator");
   if (cfg->primary_rays < 0 || cfg->primary_rays > 1)
     return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_create: bad primary_rays");
+  if (cfg->fused_trace < 0 || cfg->fused_trace > 2)
+    return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_create: bad fused_trace");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev == 0)
@@ -519,6 +522,12 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
   const size_t lds_fin = (size_t)c->stack_entries * kFinishBlock * sizeof(int) + scene_lds;
   const rtx::TraceParams tp{c->stack_entries, c->spill.p, pool};
   const bool shadows = c->scene.num_lights != 0 && c->cfg.integrator == 0;
+  // One kernel for search and shading where the tree is staged in LDS.  Every block stages the
+  // scene, so larger scenes get larger blocks (measured: 2 % for 128 threads below the limit,
+  // 14 % for 256 at a scene of 16 KB).
+  const bool fused = c->cfg.fused_trace != 1 && c->trace_mode == rtx::kLdsBvh2;
+  const int fused_block = c->lds_scene_bytes <= kFusedSmallSceneBytes ? 128 : 256;
+  const size_t lds_fused = (size_t)c->stack_entries * fused_block * sizeof(int) + scene_lds;
   LaunchTimer lt(c, st, timer);
   uint64_t launches = 0, iterations = 0;
 
@@ -579,6 +588,17 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
     uint32_t rpw = 64;
     while (rpw < kRaysPerWaveMax && (unsigned long long)active_upper / (2 * rpw) >= kWaveSlotsTarget) rpw *= 2;
     const uint32_t gxi = std::max(1u, div_up(seg_max_upper, rpw * (kTraceBlock / 64)));
+    if (fused) {
+      lt.begin(kShade, active_upper);
+      if (fused_block == 128)
+        rtx::k_trace_shade<128, rtx::kLdsBvh2><<<dim3(div_up(seg_max_upper, 128), nseg), 128, lds_fused, st>>>(
+            c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp);
+      else
+        rtx::k_trace_shade<256, rtx::kLdsBvh2><<<dim3(div_up(seg_max_upper, 256), nseg), 256, lds_fused, st>>>(
+            c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp);
+      lt.end();
+      launches++;
+    } else {
     lt.begin(kIsect, active_upper);
     if (c->trace_mode == rtx::kGlobalBvh4) {
       rtx::k_intersect_wide<kTraceBlock><<<dim3(gxi, nseg), kTraceBlock, lds, st>>>(c->scene, qc, c->hits.p, seg, cur,
@@ -597,6 +617,7 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
                                                                  c->res.p, prp);
     lt.end();
     launches += 2;
+    }
     if (shadows) {
       lt.begin(kShadow, active_upper);
       RTX_BY_MODE(c->trace_mode, rtx::k_shadow, kTraceBlock, (dim3(gx128, nseg), kTraceBlock, lds, st),

@@ -27,6 +27,7 @@ def random_case(seed):
     cfg = dict(width=int(rng.integers(3, 90)), height=int(rng.integers(3, 70)), sky=int(rng.integers(0, 2)),
                camera=cam, fov=60.0 if cam == 1 else 50.0, pool_paths=int(rng.choice([256, 700, 4096, 1 << 15])),
                finish_paths=int(rng.choice([0, 1, 64])), max_bounces=int(rng.choice([0, 0, 5])))
+    cfg["fused_trace"] = int(rng.integers(0, 2))   # small scenes: one kernel per bounce, or search and shading apart
     return sc, cfg
 
 

@@ -151,6 +151,25 @@ def test_recomputed_and_stored_primary_rays_give_the_same_bits(camera, rtx_lib):
         assert np.array_equal(c.view(np.uint32), d.view(np.uint32)) and sc_.bounces == sd.bounces
 
 
+@pytest.mark.parametrize("camera", [0, 1, 2], ids=["perspective", "thin_lens", "orthogonal"])
+def test_one_kernel_and_two_kernel_bounces_give_the_same_bits(camera, rtx_lib):
+    """Scenes whose tree is staged in LDS search and shade in one kernel (fused_trace = 0);
+    fused_trace = 1 keeps k_intersect and k_shade apart.  Same arithmetic per path and per-sample
+    result slots, so images and counts are identical, with either source of primary rays."""
+    for sc, sky in [(scenes.cornell(), 0), (scenes.sphere_sky(glass=True), 1), (scenes.soup(150, 3, seed=2), 1)]:
+        for primary in (0, 1):
+            kw = dict(width=160, height=100, sky=sky, camera=camera, pool_paths=1 << 13, primary_rays=primary)
+            a, sa, ia = gpu_render(Config(fused_trace=0, **kw), sc, 5)
+            b, sb, _ = gpu_render(Config(fused_trace=1, **kw), sc, 5)
+            assert ia.bvh_width == 2
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+            assert (sa.paths, sa.bounces, sa.nee_samples, sa.shadow_rays) == (sb.paths, sb.bounces, sb.nee_samples, sb.shadow_rays)
+            assert sa.launches < sb.launches
+        c, sc_, _ = gpu_render(Config(fused_trace=0, max_bounces=3, integrator=0, **kw), sc, 2)
+        d, sd, _ = gpu_render(Config(fused_trace=1, max_bounces=3, integrator=0, **kw), sc, 2)
+        assert np.array_equal(c.view(np.uint32), d.view(np.uint32)) and sc_.bounces == sd.bounces
+
+
 def test_result_buffer_chunking(rtx_lib):
     """A result buffer smaller than the call's samples: the call is rendered in chunks."""
     sc = scenes.cornell()
