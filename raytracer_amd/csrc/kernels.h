@@ -75,6 +75,8 @@ struct SceneDev {
   int sky;
   uint32_t max_bounces;
   int integrator;
+  int carries_colour;  // 0: nothing in the scene emits and there are no lights, so a path's colour and
+                       // nee_pdf stay exactly 0 until it ends; the queues then skip them (s1)
 };
 
 struct CameraDev {
@@ -956,7 +958,7 @@ struct ShadowReq {
 // attenuation (1), colour (0), mis_brdf_pdf (-1) and nee_pdf are the constants
 // pathTrace starts with (Integrator.h:99-106); k_generate does not write them
 // and they are not read back (32 of the 64 bytes, on the most numerous paths).
-__device__ __forceinline__ void load_path(const Queue& q, uint32_t i, bool use_depth, bool fresh,
+__device__ __forceinline__ void load_path(const SceneDev& sc, const Queue& q, uint32_t i, bool fresh,
                                           const Primary& pr, uint32_t fresh_k, PathState& p) {
   float4 s0 = make_float4(1.0f, 1.0f, 1.0f, -1.0f);
   float4 s1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -970,26 +972,26 @@ __device__ __forceinline__ void load_path(const Queue& q, uint32_t i, bool use_d
     uint2 s2 = q.s2[i];
     if (!fresh) {
       s0 = q.s0[i];
-      s1 = q.s1[i];
+      if (sc.carries_colour) s1 = q.s1[i];
     }
     p.o = mk3(r0.x, r0.y, r0.z);
     p.d = mk3(r0.w, r1.x, r1.y);
     p.ordinal = s2.x;
     p.rng = s2.y;
-    p.depth = use_depth ? q.depth[i] : 0;
+    p.depth = sc.max_bounces ? q.depth[i] : 0;
   }
   p.att = mk3(s0.x, s0.y, s0.z);
   p.mis_pdf = s0.w;
   p.col = mk3(s1.x, s1.y, s1.z);
   p.nee_pdf = s1.w;
 }
-__device__ __forceinline__ void store_path(const Queue& q, uint32_t i, bool use_depth, const PathState& p) {
+__device__ __forceinline__ void store_path(const SceneDev& sc, const Queue& q, uint32_t i, const PathState& p) {
   q.r0[i] = make_float4(p.o.x, p.o.y, p.o.z, p.d.x);
   q.r1[i] = make_float2(p.d.y, p.d.z);
   q.s0[i] = make_float4(p.att.x, p.att.y, p.att.z, p.mis_pdf);
-  q.s1[i] = make_float4(p.col.x, p.col.y, p.col.z, p.nee_pdf);
+  if (sc.carries_colour) q.s1[i] = make_float4(p.col.x, p.col.y, p.col.z, p.nee_pdf);
   q.s2[i] = make_uint2(p.ordinal, p.rng);
-  if (use_depth) q.depth[i] = p.depth;
+  if (sc.max_bounces) q.depth[i] = p.depth;
 }
 
 // The body of the loop at reference Integrator.h:108-285 for a path whose
@@ -1450,20 +1452,19 @@ __global__ __launch_bounds__(256) void k_shade_wave_append(SceneDev sc, Queue in
   if ((j & ~63u) >= n) return;  // whole waves beyond the fill leave; partial waves stay for the ballots
   const bool active = j < n;
   const uint32_t i = s * cap + j;
-  const bool use_depth = sc.max_bounces != 0;
 
   PathState p;
   ShadowReq sr;
   bool alive = false, want_shadow = false, did_nee = false;
   if (active) {
-    load_path(in, i, use_depth, j >= seg[s].gen_slot0, *prp, (uint32_t)seg[s].gen_ordinal0 + (j - seg[s].gen_slot0), p);
+    load_path(sc, in, i, j >= seg[s].gen_slot0, *prp, (uint32_t)seg[s].gen_ordinal0 + (j - seg[s].gen_slot0), p);
     uint2 h = hits[i];
     alive = shade_bounce(sc, global_geom(sc), p, __uint_as_float(h.x), h.y, want_shadow, did_nee, sr);
     if (!alive) store_result(res, p.ordinal, p.col);
   }
   uint32_t pos, spos;
   wave_append(alive, want_shadow, did_nee, &seg[s].c[qi ^ 1], pos, spos);
-  if (alive) store_path(out, s * cap + pos, use_depth, p);
+  if (alive) store_path(sc, out, s * cap + pos, p);
   if (want_shadow) {
     const uint32_t k = s * cap + spos;
     sq.q0[k] = make_float4(p.o.x, p.o.y, p.o.z, sr.tfar);
@@ -1487,13 +1488,12 @@ __global__ __launch_bounds__(BLOCK) void k_trace_shade(SceneDev sc, Queue in, Qu
   const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
   const bool active = j < n;
   const uint32_t i = s * cap + j;
-  const bool use_depth = sc.max_bounces != 0;
 
   PathState p;
   ShadowReq sr;
   bool alive = false, want_shadow = false, did_nee = false;
   if (active) {
-    load_path(in, i, use_depth, j >= seg[s].gen_slot0, *prp, (uint32_t)seg[s].gen_ordinal0 + (j - seg[s].gen_slot0), p);
+    load_path(sc, in, i, j >= seg[s].gen_slot0, *prp, (uint32_t)seg[s].gen_ordinal0 + (j - seg[s].gen_slot0), p);
     float t;
     uint32_t id;
     cast_ray<MODE>(sc, geom, p.o, p.d, stk, t, id);
@@ -1502,7 +1502,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_shade(SceneDev sc, Queue in, Qu
   }
   uint32_t pos, spos;  // (the per-block append of k_shade_block_append measured slower here)
   wave_append(alive, want_shadow, did_nee, &seg[s].c[qi ^ 1], pos, spos);
-  if (alive) store_path(out, s * cap + pos, use_depth, p);
+  if (alive) store_path(sc, out, s * cap + pos, p);
   if (want_shadow) {
     const uint32_t k = s * cap + spos;
     sq.q0[k] = make_float4(p.o.x, p.o.y, p.o.z, sr.tfar);
@@ -1523,20 +1523,19 @@ __global__ __launch_bounds__(256) void k_shade_block_append(SceneDev sc, Queue i
   if (blockIdx.x * blockDim.x >= n) return;  // whole blocks beyond the fill leave; the rest stay for the barriers
   const bool active = j < n;
   const uint32_t i = s * cap + j;
-  const bool use_depth = sc.max_bounces != 0;
 
   PathState p;
   ShadowReq sr;
   bool alive = false, want_shadow = false, did_nee = false;
   if (active) {
-    load_path(in, i, use_depth, j >= seg[s].gen_slot0, *prp, (uint32_t)seg[s].gen_ordinal0 + (j - seg[s].gen_slot0), p);
+    load_path(sc, in, i, j >= seg[s].gen_slot0, *prp, (uint32_t)seg[s].gen_ordinal0 + (j - seg[s].gen_slot0), p);
     uint2 h = hits[i];
     alive = shade_bounce(sc, global_geom(sc), p, __uint_as_float(h.x), h.y, want_shadow, did_nee, sr);
     if (!alive) store_result(res, p.ordinal, p.col);
   }
   uint32_t pos, spos;
   block_append(alive, want_shadow, did_nee, &seg[s].c[qi ^ 1], pos, spos);
-  if (alive) store_path(out, s * cap + pos, use_depth, p);
+  if (alive) store_path(sc, out, s * cap + pos, p);
   if (want_shadow) {
     const uint32_t k = s * cap + spos;
     sq.q0[k] = make_float4(p.o.x, p.o.y, p.o.z, sr.tfar);
@@ -1592,7 +1591,7 @@ __global__ __launch_bounds__(BLOCK) void k_finish(SceneDev sc, Queue q, const Se
   uint32_t nb = 0, nn = 0, ns = 0;
   if (active) {
     PathState p;
-    load_path(q, s * cap + j, sc.max_bounces != 0, j >= seg[s].gen_slot0, *prp,
+    load_path(sc, q, s * cap + j, j >= seg[s].gen_slot0, *prp,
               (uint32_t)seg[s].gen_ordinal0 + (j - seg[s].gen_slot0), p);
     for (uint32_t it = 0; it < kFinishCap; it++) {
       float t;

@@ -421,6 +421,10 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
   d.sky = c->cfg.sky;
   d.max_bounces = c->cfg.max_bounces;
   d.integrator = c->cfg.integrator;
+  bool emits = !l0.empty();
+  for (const float4& m : m0) emits = emits || m.w > 0.0f;
+  for (const float4& m : sp1) emits = emits || m.w > 0.0f;
+  d.carries_colour = emits ? 1 : 0;
   c->stack_entries = stack_entries;
   c->lds_scene_bytes = (nodes.size() + 4 * nt) * sizeof(float4);
   if (bvh.width == 4)

@@ -170,6 +170,23 @@ def test_one_kernel_and_two_kernel_bounces_give_the_same_bits(camera, rtx_lib):
         assert np.array_equal(c.view(np.uint32), d.view(np.uint32)) and sc_.bounces == sd.bounces
 
 
+def test_scenes_without_emitters_skip_the_colour_state_and_keep_their_bits(oracle, rtx_lib):
+    """Where no material emits and there are no lights a live path's colour is exactly 0, and the queues
+    do not carry it.  An emissive material that no surface uses switches the skipping off: same image."""
+    for fused in (0, 1):
+        for sc in (scenes.sphere_sky(glass=True), scenes.sphere_sky(glass=False)):
+            kw = dict(width=150, height=90, sky=1, pool_paths=1 << 12, fused_trace=fused)
+            a, sa, _ = gpu_render(Config(**kw), sc, 6)
+            lit = scenes.SceneData(sc.triangles, sc.material_index,
+                                   np.concatenate([sc.materials, np.array([scenes.material((1, 1, 1), 3.0)], scenes.MATERIAL_DTYPE)]),
+                                   sc.spheres, name="with_unused_emitter")
+            b, sb, ib = gpu_render(Config(**kw), lit, 6)
+            assert ib.num_lights == 0
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)) and sa.bounces == sb.bounces
+            want, ost = oracle.OracleScene(sc, Config(**kw)).render(6)
+            assert sa.paths == ost.paths and close_fraction(a, want) >= 0.98
+
+
 def test_result_buffer_chunking(rtx_lib):
     """A result buffer smaller than the call's samples: the call is rendered in chunks."""
     sc = scenes.cornell()
