@@ -421,6 +421,26 @@ struct ClosestHit {
 // holds a leaf (or is done), then all test triangles; the two phases do not mix
 // within an iteration, which keeps more lanes busy in each.
 
+// One two-child node of a closest-hit walk: the nearer child next, the other pushed.
+__device__ __forceinline__ void closest_node_step(const Geom& g, const Stack& stk, Walk& w, const ClosestHit& best) {
+  const float4* nd = g.nodes + 4 * (size_t)w.cur;
+  float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
+  float tn0, tn1;
+  bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, w.inv, w.add_lo, w.add_hi, best.t, tn0);
+  bool h1 = slab(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, w.inv, w.add_lo, w.add_hi, best.t, tn1);
+  int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+  if (h0 && h1) {
+    bool swap = tn1 < tn0;
+    stk.push(w.sp, swap ? c0 : c1);
+    w.cur = swap ? c1 : c0;
+  } else if (h0) {
+    w.cur = c0;
+  } else if (h1) {
+    w.cur = c1;
+  } else {
+    w.cur = w.sp == 0 ? kTraversalDone : stk.pop(w.sp);
+  }
+}
 // Inner nodes of a closest-hit walk: front to back, until the lane reaches a leaf.
 template <int MODE>
 __device__ __forceinline__ void closest_nodes(const Geom& g, const Stack& stk, Walk& w, const ClosestHit& best) {
@@ -448,25 +468,7 @@ __device__ __forceinline__ void closest_nodes(const Geom& g, const Stack& stk, W
       }
     }
   } else {
-    while (w.cur >= 0) {
-      const float4* nd = g.nodes + 4 * (size_t)w.cur;
-      float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
-      float tn0, tn1;
-      bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, w.inv, w.add_lo, w.add_hi, best.t, tn0);
-      bool h1 = slab(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, w.inv, w.add_lo, w.add_hi, best.t, tn1);
-      int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-      if (h0 && h1) {
-        bool swap = tn1 < tn0;
-        stk.push(w.sp, swap ? c0 : c1);
-        w.cur = swap ? c1 : c0;
-      } else if (h0) {
-        w.cur = c0;
-      } else if (h1) {
-        w.cur = c1;
-      } else {
-        w.cur = w.sp == 0 ? kTraversalDone : stk.pop(w.sp);
-      }
-    }
+    while (w.cur >= 0) closest_node_step(g, stk, w, best);
   }
 }
 // Leaves of a closest-hit walk: until the lane pops an inner node or runs out.
