@@ -46,6 +46,7 @@ constexpr uint32_t kSegmentTarget = 8192;        // aim for this many slots per 
 constexpr uint32_t kMaxSegments = 512;
 constexpr int kTraceBlock = 128;                 // threads per block of the traversal kernels
 constexpr size_t kLdsSceneMaxBytes = 16 * 1024;  // stage BVH + triangles in LDS up to this size
+constexpr size_t kLdsLaunchMaxBytes = 64 * 1024;  // dynamic LDS a launch may ask for without raising the kernel's limit
 constexpr int kWideLdsStack = 16;                // LDS stack entries per lane for the four-child tree
 constexpr int kFinishBlock = 64;
 constexpr size_t kFusedSmallSceneBytes = 4096;  // k_trace_shade: scenes up to this size run 128-thread blocks
@@ -429,8 +430,9 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
   c->lds_scene_bytes = (nodes.size() + 4 * nt) * sizeof(float4);
   if (bvh.width == 4)
     c->trace_mode = rtx::kGlobalBvh4;
-  else if (nt > 0 && c->lds_scene_bytes <= kLdsSceneMaxBytes)
-    c->trace_mode = rtx::kLdsBvh2;
+  else if (nt > 0 && c->lds_scene_bytes <= kLdsSceneMaxBytes && !std::getenv("RTX_NO_LDS_SCENE") &&  // (test hook)
+           (size_t)stack_entries * kTraceBlock * sizeof(int) + c->lds_scene_bytes <= kLdsLaunchMaxBytes)
+    c->trace_mode = rtx::kLdsBvh2;  // (a very deep small tree leaves the LDS to the stacks and stays in global memory)
   else
     c->trace_mode = rtx::kGlobalBvh2;
   c->have_scene = true;
@@ -530,7 +532,10 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
   // scene, so larger scenes get larger blocks (measured: 2 % for 128 threads below the limit,
   // 14 % for 256 at a scene of 16 KB).
   const bool fused = c->cfg.fused_trace != 1 && c->trace_mode == rtx::kLdsBvh2;
-  const int fused_block = c->lds_scene_bytes <= kFusedSmallSceneBytes ? 128 : 256;
+  const int fused_block = c->lds_scene_bytes <= kFusedSmallSceneBytes ||
+                                  (size_t)c->stack_entries * 256 * sizeof(int) + scene_lds > kLdsLaunchMaxBytes
+                              ? 128
+                              : 256;
   const size_t lds_fused = (size_t)c->stack_entries * fused_block * sizeof(int) + scene_lds;
   LaunchTimer lt(c, st, timer);
   uint64_t launches = 0, iterations = 0;

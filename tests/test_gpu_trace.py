@@ -82,6 +82,37 @@ def test_closest_hit_bit_exact(name, oracle, rtx_lib):
             assert_same_hits(got, want)
 
 
+def test_two_child_tree_in_global_memory(oracle, rtx_lib, monkeypatch):
+    """A small scene whose tree is too deep for the LDS budget keeps its two-child tree in global
+    memory.  RTX_NO_LDS_SCENE forces that mode for an ordinary small scene: same hits, same
+    occlusion answers and the same image bits as the LDS mode."""
+    cfg = Config(width=120, height=80, pool_paths=1 << 12)
+    for sc in (scenes.cornell(), scenes.soup(150, 3, seed=2)):
+        osc = oracle.OracleScene(sc, cfg)
+        rays = np.concatenate([scenes.random_rays(8000, seed=11), bounce_rays(oracle, osc, camera_rays(oracle, cfg, 48))])
+        dist = np.random.default_rng(5).uniform(0.0, 3.0, rays.shape[0]).astype(np.float32)
+        out = {}
+        for mode in ("lds", "global"):
+            if mode == "global":
+                monkeypatch.setenv("RTX_NO_LDS_SCENE", "1")
+            else:
+                monkeypatch.delenv("RTX_NO_LDS_SCENE", raising=False)
+            with Renderer(cfg) as r:
+                info = r.set_scene(sc)
+                assert info.bvh_width == 2
+                hits = r.trace_closest(rays)
+                occ = r.trace_occluded(rays, dist)
+                acc = r.accum_alloc()
+                r.render(acc, 3)
+                out[mode] = (hits, occ, r.resolve(acc, 1), r.stats())
+        monkeypatch.delenv("RTX_NO_LDS_SCENE", raising=False)
+        assert_same_hits(out["global"][0], osc.trace_closest(rays, use_bvh=False))
+        assert np.array_equal(out["global"][1], osc.trace_occluded(rays, dist, use_bvh=False))
+        assert np.array_equal(out["global"][2].view(np.uint32), out["lds"][2].view(np.uint32))
+        assert out["global"][3].bounces == out["lds"][3].bounces
+        assert out["global"][3].launches > out["lds"][3].launches     # no one-kernel bounce without the LDS tree
+
+
 @pytest.mark.parametrize("name", ["cornell", "soup10k", "sphere_sky", "spheres_only", "ref_scene0", "ref_scene1"])
 def test_occlusion_bit_exact(name, oracle, rtx_lib):
     cfg = Config(width=800, height=800, pool_paths=1 << 16)
