@@ -219,6 +219,12 @@ int rtx_set_profiling(rtx_ctx* ctx, int on);
 int rtx_accum_alloc(rtx_ctx* ctx, float** accum_dev_out);
 int rtx_accum_free(rtx_ctx* ctx, float* accum_dev);
 int rtx_accum_clear(rtx_ctx* ctx, float* accum_dev, void* stream);
+/* Restores the state Img carries between passes (Img::pixels and Img::sample_count,
+ * Raytracer.cpp:49-59) from a checkpoint: copies width*height*3 per-pixel SUMS from the host
+ * into accum_dev.  The sums are what rtx_resolve returns for total_spp = 1; a render resumed
+ * with sample_base = the number of samples they hold gives the bits of an uninterrupted one.
+ * Synchronous. */
+int rtx_accum_upload(rtx_ctx* ctx, float* accum_dev, const float* sums_host, void* stream);
 
 #ifdef __cplusplus
 }

@@ -94,6 +94,7 @@ SYMBOLS = [
     "rtx_last_error", "rtx_create", "rtx_destroy", "rtx_set_scene", "rtx_get_scene_info",
     "rtx_render", "rtx_resolve", "rtx_trace_closest", "rtx_trace_occluded", "rtx_get_stats",
     "rtx_reset_stats", "rtx_set_profiling", "rtx_accum_alloc", "rtx_accum_free", "rtx_accum_clear",
+    "rtx_accum_upload",
 ]
 
 _lib = None
@@ -129,6 +130,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rtx_accum_alloc.argtypes = [vp, C.POINTER(vp)]
     lib.rtx_accum_free.argtypes = [vp, vp]
     lib.rtx_accum_clear.argtypes = [vp, vp, vp]
+    lib.rtx_accum_upload.argtypes = [vp, vp, vp, vp]
     if path is None:
         _lib = lib
     return lib
@@ -282,6 +284,12 @@ class Renderer:
 
     def accum_clear(self, accum, stream: int = 0):
         self._check(self.lib.rtx_accum_clear(self._ctx, _dev_ptr(accum), stream))
+
+    def accum_upload(self, accum, sums: np.ndarray, stream: int = 0):
+        """Per-pixel sums (H, W, 3) from a checkpoint into the device buffer."""
+        a = np.ascontiguousarray(sums, np.float32)
+        assert a.size == self.cfg.width * self.cfg.height * 3
+        self._check(self.lib.rtx_accum_upload(self._ctx, _dev_ptr(accum), _ptr(a), stream))
 
     # -- rendering ---------------------------------------------------------------
     def render(self, accum, spp: int, sample_base: int = 0, seed: int = 0x5EED,

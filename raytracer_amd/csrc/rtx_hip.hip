@@ -926,4 +926,14 @@ int rtx_accum_clear(rtx_ctx* c, float* p, void* stream) {
   return RTX_OK;
 }
 
+int rtx_accum_upload(rtx_ctx* c, float* p, const float* sums_host, void* stream) {
+  if (!c || !p || !sums_host) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_accum_upload: null argument");
+  DeviceGuard g(c->device);
+  if (!g.ok) return fail(RTX_ERR_HIP, "rtx_accum_upload: hipSetDevice failed");
+  size_t bytes = (size_t)c->cfg.width * c->cfg.height * 3 * sizeof(float);
+  HIP_TRY(hipMemcpyAsync(p, sums_host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return RTX_OK;
+}
+
 }  // extern "C"

@@ -3,7 +3,12 @@
 // render_loop (Raytracer.cpp:307-331), saving the image instead of showing a window.
 //
 //   rt_host [--obj FILE] [--width W] [--height H] [--spp N] [--passes P] [--sky]
-//           [--out PREFIX] [--parse-only]
+//           [--out PREFIX] [--checkpoint FILE] [--resume FILE] [--parse-only]
+//           [--pfm-to-exr IN OUT]
+//
+// --checkpoint writes the per-pixel sums and the sample count after the last pass; --resume
+// starts from such a file and goes on with the next sample index, so that two runs of P passes
+// end with the bits of one run of 2P.
 //
 // Without --obj the live scene's roles are built procedurally (the reference's
 // geometry/CornellBox-Original.obj is not part of its repository): red/green/white walls,
@@ -40,7 +45,7 @@ int main(int argc, char** argv) {
   std::string obj, out = "render";
   uint32_t width = 800, height = 800, spp = 16, passes = 1;
   bool sky = false, parse_only = false;
-  std::string pfm_in, exr_out;
+  std::string pfm_in, exr_out, resume, checkpoint;
   for (int i = 1; i < argc; i++) {
     auto next = [&](const char* name) -> const char* {
       if (i + 1 >= argc) {
@@ -57,6 +62,8 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--out")) out = next("--out");
     else if (!std::strcmp(argv[i], "--sky")) sky = true;
     else if (!std::strcmp(argv[i], "--parse-only")) parse_only = true;
+    else if (!std::strcmp(argv[i], "--resume")) resume = next("--resume");
+    else if (!std::strcmp(argv[i], "--checkpoint")) checkpoint = next("--checkpoint");
     else if (!std::strcmp(argv[i], "--pfm-to-exr")) {
       pfm_in = next("--pfm-to-exr");
       exr_out = next("--pfm-to-exr");
@@ -116,6 +123,10 @@ int main(int argc, char** argv) {
 
     Img img(width, height);
     clear(img, scene);
+    if (!resume.empty()) {
+      load_checkpoint(img, scene, resume.c_str());
+      std::printf("Resumed %s at %u samples per pixel\n", resume.c_str(), img.sample_count);
+    }
     auto t0 = std::chrono::high_resolution_clock::now();
     for (uint32_t p = 0; p < passes; p++) {
       auto tp = std::chrono::high_resolution_clock::now();
@@ -127,6 +138,7 @@ int main(int argc, char** argv) {
       float total = std::chrono::duration<float>(std::chrono::high_resolution_clock::now() - t0).count();
       std::printf("Accumulated %u samples per pixel over %f seconds\n\n", img.sample_count, total);
     }
+    if (!checkpoint.empty()) save_checkpoint(img, scene, checkpoint.c_str());
     rtx_stats st;
     check(rtx_get_stats(scene.ctx(), &st), "rtx_get_stats");
     std::printf("paths %llu, path-bounces %llu, shadow rays %llu\n", (unsigned long long)st.paths,

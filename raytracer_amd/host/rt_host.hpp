@@ -476,10 +476,12 @@ class Img {
   void set(int px, int py, Vec3 v) { pixels[idx(px, py)] = v; }
 
   // Float image, bottom row first (PFM convention), little endian.
-  bool savePFM(const char* path) const {
+  // `scale` is the magnitude of the PFM scale line (its sign says little endian); checkpoints
+  // keep the sample count there.
+  bool savePFM(const char* path, float scale = 1.0f) const {
     FILE* f = std::fopen(path, "wb");
     if (!f) return false;
-    std::fprintf(f, "PF\n%u %u\n-1.0\n", width, height);
+    std::fprintf(f, "PF\n%u %u\n-%.9g\n", width, height, (double)scale);
     for (uint32_t y = height; y-- > 0;) std::fwrite(&pixels[(size_t)y * width], sizeof(Vec3), width, f);
     return std::fclose(f) == 0;
   }
@@ -576,7 +578,7 @@ class Img {
     return (std::fclose(f) == 0) && ok;
   }
   // Reads what savePFM wrote (or any little-endian RGB PFM) back into pixels.
-  bool loadPFM(const char* path) {
+  bool loadPFM(const char* path, float* scale_out = nullptr) {
     FILE* f = std::fopen(path, "rb");
     if (!f) return false;
     unsigned w = 0, h = 0;
@@ -592,6 +594,7 @@ class Img {
         ok = std::fread(&pixels[(size_t)y * width], sizeof(Vec3), width, f) == width;
     }
     std::fclose(f);
+    if (ok && scale_out) *scale_out = -scale;
     return ok;
   }
   // 8-bit sRGB with the reference's transfer function (Vec3.cpp:39-53): clamp to 1, then
@@ -627,6 +630,26 @@ inline void render(Img& img, Scene& scene, uint32_t spp = 1, uint64_t seed = 0x5
   const float off[3] = {pos.x, pos.y, pos.z};
   check(rtx_render(scene.ctx(), scene.accum(), spp, img.sample_count, seed, off, 0, 0, nullptr), "rtx_render");
   img.sample_count += spp;
+  check(rtx_resolve(scene.ctx(), scene.accum(), img.sample_count, &img.pixels[0].x, nullptr), "rtx_resolve");
+}
+
+// Checkpoint of an accumulation in progress -- what Img holds between passes (Img::pixels as sums,
+// Img::sample_count; Raytracer.cpp:49-59): a PFM of the per-pixel sums whose scale line carries
+// the sample count.  A render resumed from it continues with the next sample index and ends
+// with the bits of an uninterrupted one.
+inline void save_checkpoint(const Img& img, Scene& scene, const char* path) {
+  Img sums(img.width, img.height);
+  check(rtx_resolve(scene.ctx(), scene.accum(), 1, &sums.pixels[0].x, nullptr), "rtx_resolve");
+  if (!sums.savePFM(path, (float)img.sample_count)) throw Error(std::string("cannot write ") + path);
+}
+inline void load_checkpoint(Img& img, Scene& scene, const char* path) {
+  Img sums(1, 1);
+  float count = 0;
+  if (!sums.loadPFM(path, &count)) throw Error(std::string("cannot read ") + path);
+  if (sums.width != img.width || sums.height != img.height || !(count >= 1.0f) || count != std::floor(count))
+    throw Error(std::string("checkpoint ") + path + " does not fit this image");
+  check(rtx_accum_upload(scene.ctx(), scene.accum(), &sums.pixels[0].x, nullptr), "rtx_accum_upload");
+  img.sample_count = (uint32_t)count;
   check(rtx_resolve(scene.ctx(), scene.accum(), img.sample_count, &img.pixels[0].x, nullptr), "rtx_resolve");
 }
 

@@ -187,6 +187,27 @@ def test_scenes_without_emitters_skip_the_colour_state_and_keep_their_bits(oracl
             assert sa.paths == ost.paths and close_fraction(a, want) >= 0.98
 
 
+def test_uploaded_sums_resume_a_render(rtx_lib):
+    """rtx_accum_upload: the sums of 5 samples, taken to the host and put into another context's
+    buffer, then 4 more samples from index 5 = 9 samples in one call."""
+    sc = scenes.cornell()
+    cfg = Config(width=90, height=60, pool_paths=1 << 13)
+    whole, _, _ = gpu_render(cfg, sc, 9)
+    with Renderer(cfg) as r:
+        r.set_scene(sc)
+        acc = r.accum_alloc()
+        r.render(acc, 5)
+        sums = r.resolve(acc, 1)
+    with Renderer(cfg) as r:
+        r.set_scene(sc)
+        acc = r.accum_alloc()
+        r.accum_upload(acc, sums)
+        assert np.array_equal(r.resolve(acc, 1).view(np.uint32), sums.view(np.uint32))
+        r.render(acc, 4, sample_base=5)
+        got = r.resolve(acc, 1)
+    assert np.array_equal(got.view(np.uint32), whole.view(np.uint32))
+
+
 def test_result_buffer_chunking(rtx_lib):
     """A result buffer smaller than the call's samples: the call is rendered in chunks."""
     sc = scenes.cornell()

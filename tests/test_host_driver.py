@@ -95,3 +95,22 @@ def test_driver_render_equals_python_binding(rt_host, tmp_path):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     ppm = open(out + ".ppm", "rb").read()
     assert ppm.startswith(b"P6\n64 48\n255\n") and len(ppm) == 13 + 64 * 48 * 3
+
+
+@pytest.mark.gpu
+def test_driver_checkpoint_and_resume_equal_one_run(rt_host, tmp_path):
+    """Two runs of two passes, the second resumed from the first's checkpoint, write the image of one
+    run of four passes, bit for bit (sums, sample count and sample indices carry over)."""
+    common = [rt_host, "--width", "72", "--height", "40", "--spp", "3"]
+    subprocess.check_call(common + ["--passes", "4", "--out", str(tmp_path / "whole")], stdout=subprocess.DEVNULL)
+    subprocess.check_call(common + ["--passes", "2", "--out", str(tmp_path / "half"),
+                                    "--checkpoint", str(tmp_path / "half.ckpt")], stdout=subprocess.DEVNULL)
+    log = subprocess.check_output(common + ["--passes", "2", "--out", str(tmp_path / "resumed"),
+                                            "--resume", str(tmp_path / "half.ckpt")]).decode()
+    assert "Resumed" in log and "at 6 samples per pixel" in log and "Accumulated 12 samples per pixel" in log
+    whole, half, resumed = (read_pfm(str(tmp_path / n) + ".pfm") for n in ("whole", "half", "resumed"))
+    assert np.array_equal(whole.view(np.uint32), resumed.view(np.uint32))
+    assert not np.array_equal(whole, half)
+    assert (tmp_path / "resumed.exr").read_bytes() == (tmp_path / "whole.exr").read_bytes()
+    r = subprocess.run(common + ["--width", "64", "--resume", str(tmp_path / "half.ckpt")], capture_output=True)
+    assert r.returncode == 1 and b"does not fit" in r.stderr
