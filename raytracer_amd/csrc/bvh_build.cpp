@@ -3,15 +3,19 @@
 #include "bvh_build.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <thread>
 
 namespace rtx {
 namespace {
 
 constexpr int kBins = 16;
 constexpr uint32_t kMaxSahDepth = 40;  // below this depth, fall back to median splits
+constexpr size_t kParallelMinTriangles = 1u << 16;  // smaller meshes build on the calling thread
+constexpr size_t kParallelSubtrees = 128;           // subtrees of at most ntri/128 triangles go to workers
 
 struct Box {
   float lo[3], hi[3];
@@ -54,12 +58,25 @@ struct Builder {
 
   uint32_t kMaxLeaf;  // a node with more triangles is always split
 
+  // Top of a parallel build: a subtree of at most `defer_below` triangles is not built but
+  // noted in `deferred` (its root stays a placeholder) for a worker to build on its own.
+  struct Deferred {
+    int32_t node;
+    uint32_t first, count, depth;
+  };
+  uint32_t defer_below = 0;
+  std::vector<Deferred> deferred;
+
   Builder(const std::vector<Box>& tb_, const std::vector<float>& c_, std::vector<uint32_t>& o_, uint32_t max_leaf)
       : tb(tb_), cent(c_), order(o_), kMaxLeaf(max_leaf) {}
 
   int32_t build(uint32_t first, uint32_t count, uint32_t depth) {
     int32_t id = (int32_t)nodes.size();
     nodes.emplace_back();
+    if (count <= defer_below && count > kMaxLeaf) {
+      deferred.push_back({id, first, count, depth});
+      return id;
+    }
     Box box, cbox;
     box.reset();
     cbox.reset();
@@ -330,7 +347,43 @@ void build_bvh(const float* tris, size_t ntri, uint32_t max_leaf, uint32_t width
   for (size_t i = 0; i < ntri; i++) out.order[i] = (uint32_t)i;
   Builder b(tb, cent, out.order, kMaxLeaf);
   b.nodes.reserve(ntri);
+  // Large meshes: the top of the tree here, the subtrees below it on worker threads.  Each worker
+  // permutes only its own range of `order`, and the subtrees are spliced in in a fixed order, so
+  // the tree does not depend on the number of threads.
+  const uint32_t workers = ntri >= kParallelMinTriangles ? std::min(16u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+  if (workers > 1) b.defer_below = (uint32_t)(ntri / kParallelSubtrees);
   int32_t root = b.build(0, (uint32_t)ntri, 0);
+  if (!b.deferred.empty()) {
+    std::vector<std::vector<TmpNode>> sub(b.deferred.size());
+    std::atomic<size_t> next_task{0};
+    auto work = [&]() {
+      for (size_t k; (k = next_task.fetch_add(1)) < b.deferred.size();) {
+        const Builder::Deferred& d = b.deferred[k];
+        Builder w(tb, cent, out.order, kMaxLeaf);
+        w.nodes.reserve(d.count);
+        w.build(d.first, d.count, d.depth);
+        sub[k] = std::move(w.nodes);
+      }
+    };
+    std::vector<std::thread> pool;
+    for (uint32_t t = 1; t < workers; t++) pool.emplace_back(work);
+    work();
+    for (std::thread& t : pool) t.join();
+    for (size_t k = 0; k < sub.size(); k++) {
+      // local node 0 takes the placeholder's place, local node i > 0 goes to base + i - 1
+      const int32_t base = (int32_t)b.nodes.size();
+      auto moved = [&](int32_t child) { return child < 0 ? child : base + child - 1; };
+      for (size_t i = 0; i < sub[k].size(); i++) {
+        TmpNode n = sub[k][i];
+        n.left = moved(n.left);
+        n.right = moved(n.right);
+        if (i == 0)
+          b.nodes[b.deferred[k].node] = n;
+        else
+          b.nodes.push_back(n);
+      }
+    }
+  }
 
   // Leaves keep their triangles in ascending primitive order (helps the
   // lowest-index tie-break find the winner first).
