@@ -1657,6 +1657,80 @@ __global__ __launch_bounds__(256) void k_reduce(const float* res, float* accum, 
   accum[f] = acc;
 }
 
+// The ordered sum split in two so that most of it can run beside k_finish, which keeps a few
+// waves busy for a long time and leaves the memory system idle.
+//  k_mark_unfinished  writes a marker (a NaN with a payload no arithmetic produces) into the
+//                     result slots of the paths k_finish is about to run;
+//  k_reduce_head      (other stream, beside k_finish) adds each float's samples in order up to its
+//                     first marker and notes where it stopped; a slot k_finish fills meanwhile
+//                     reads as marker or as result, and both are handled;
+//  k_reduce_tail      (after both) goes on from there for the floats that were stopped.
+// Every float's additions stay in sample order, so the sums keep the bits of k_reduce.
+constexpr uint32_t kUnfinishedBits = 0x7fc0deadu;
+__global__ __launch_bounds__(64) void k_mark_unfinished(Queue q, const SegCounter* seg, int qi, uint32_t cap,
+                                                        float* res, const Primary* __restrict__ prp) {
+  const uint32_t s = blockIdx.y;
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= seg_paths(seg[s].c[qi])) return;
+  const uint32_t g0 = seg[s].gen_slot0;
+  const uint32_t ordinal =
+      (j >= g0 && prp->recompute) ? (uint32_t)seg[s].gen_ordinal0 + (j - g0) : q.s2[(size_t)s * cap + j].x;
+  float* dst = res + 3 * (size_t)ordinal;
+  const float marker = __uint_as_float(kUnfinishedBits);
+  dst[0] = marker;
+  dst[1] = marker;
+  dst[2] = marker;
+}
+__device__ __forceinline__ void add_until_marker(float v, uint32_t s, float& acc, uint32_t& stop, uint32_t none) {
+  if (stop == none) {
+    if (__float_as_uint(v) == kUnfinishedBits)
+      stop = s;
+    else
+      acc += v;
+  }
+}
+// nfloats is a multiple of four; stop4[f] receives, per float, the sample it stopped at (spp_chunk = none).
+__global__ __launch_bounds__(256) void k_reduce_head(const float* res, float* accum, uint4* stop4, uint32_t nfloats,
+                                                     uint32_t spp_chunk) {
+  const uint32_t n4 = nfloats >> 2;
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n4) return;
+  float4 acc = reinterpret_cast<const float4*>(accum)[f];
+  uint4 stop = make_uint4(spp_chunk, spp_chunk, spp_chunk, spp_chunk);
+  const float4* src = reinterpret_cast<const float4*>(res) + f;
+#pragma unroll 8
+  for (uint32_t s = 0; s < spp_chunk; s++) {
+    float4 v = src[(size_t)s * n4];
+    add_until_marker(v.x, s, acc.x, stop.x, spp_chunk);
+    add_until_marker(v.y, s, acc.y, stop.y, spp_chunk);
+    add_until_marker(v.z, s, acc.z, stop.z, spp_chunk);
+    add_until_marker(v.w, s, acc.w, stop.w, spp_chunk);
+  }
+  reinterpret_cast<float4*>(accum)[f] = acc;
+  stop4[f] = stop;
+}
+__global__ __launch_bounds__(256) void k_reduce_tail(const float* res, float* accum, const uint4* stop4,
+                                                     uint32_t nfloats, uint32_t spp_chunk) {
+  const uint32_t n4 = nfloats >> 2;
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n4) return;
+  const uint4 stop = stop4[f];
+  uint32_t first = stop.x < stop.y ? stop.x : stop.y;
+  first = first < stop.z ? first : stop.z;
+  first = first < stop.w ? first : stop.w;
+  if (first >= spp_chunk) return;
+  float4 acc = reinterpret_cast<const float4*>(accum)[f];
+  const float4* src = reinterpret_cast<const float4*>(res) + f;
+  for (uint32_t s = first; s < spp_chunk; s++) {
+    float4 v = src[(size_t)s * n4];
+    if (s >= stop.x) acc.x += v.x;
+    if (s >= stop.y) acc.y += v.y;
+    if (s >= stop.z) acc.z += v.z;
+    if (s >= stop.w) acc.w += v.w;
+  }
+  reinterpret_cast<float4*>(accum)[f] = acc;
+}
+
 // ----------------------------------------------------------------------------
 // Fixed-ray-set kernels (parity entry points).
 

@@ -49,6 +49,11 @@ constexpr size_t kLdsSceneMaxBytes = 16 * 1024;  // stage BVH + triangles in LDS
 constexpr size_t kLdsLaunchMaxBytes = 64 * 1024;  // dynamic LDS a launch may ask for without raising the kernel's limit
 constexpr int kWideLdsStack = 16;                // LDS stack entries per lane for the four-child tree
 constexpr int kFinishBlock = 64;
+#ifndef RTX_OVERLAP_REDUCE
+#define RTX_OVERLAP_REDUCE 1
+#endif
+constexpr bool kOverlapReduce = RTX_OVERLAP_REDUCE != 0;
+constexpr unsigned long long kOverlapMinSamples = 1ull << 26;
 constexpr size_t kFusedSmallSceneBytes = 4096;  // k_trace_shade: scenes up to this size run 128-thread blocks
 constexpr uint32_t kTraceBatches = 2;  // ray batches per block of k_intersect/k_shadow (the next batch's loads overlap the current traversal)
 constexpr int kPollSlots = 4;
@@ -113,6 +118,11 @@ struct rtx_ctx {
   hipEvent_t poll_ev[kPollSlots]{};
   DevBuf<float> resolve_tmp;
   DevBuf<float> res;  // per-sample results of the chunk being rendered (grown on demand)
+  // The ordered sum runs beside the drain kernel on a stream of its own (see k_reduce_head).
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  DevBuf<uint4> stop4;  // per float of the image: the sample k_reduce_head stopped at
+  unsigned long long overlap_min_samples = 0;  // chunks of at least this many samples split the sum
 
   // stats
   rtx_stats stats{};
@@ -172,6 +182,10 @@ void free_ctx(rtx_ctx* c) {
   for (int i = 0; i < kPollSlots; i++)
     if (c->poll_ev[i]) (void)hipEventDestroy(c->poll_ev[i]);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+  c->stop4.release();
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+  if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+  if (c->side) (void)hipStreamDestroy(c->side);
   delete c;
 }
 
@@ -271,6 +285,12 @@ int rtx_create(const rtx_config* cfg, rtx_ctx** out) {
   CTX_TRY(hipHostMalloc((void**)&c->h_sum, sizeof(rtx::Summary) * kPollSlots, hipHostMallocDefault));
   for (int i = 0; i < kPollSlots; i++) CTX_TRY(hipEventCreateWithFlags(&c->poll_ev[i], hipEventDisableTiming));
   CTX_TRY(c->resolve_tmp.alloc(npix * 3));
+  CTX_TRY(c->stop4.alloc((npix * 3 + 3) / 4));
+  c->overlap_min_samples = kOverlapMinSamples;
+  if (const char* e = std::getenv("RTX_OVERLAP_MIN_SAMPLES")) c->overlap_min_samples = std::strtoull(e, nullptr, 10);  // (test hook)
+  CTX_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  CTX_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  CTX_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
 #undef CTX_TRY
   *out = c;
   return RTX_OK;
@@ -537,6 +557,11 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
                               ? 128
                               : 256;
   const size_t lds_fused = (size_t)c->stack_entries * fused_block * sizeof(int) + scene_lds;
+  const uint32_t nfloats = rp.band_pixels * 3;
+  // (not while launches are being timed one by one: the two halves of the sum would not add up to a stage)
+  // (and not for small chunks: the extra launches and events cost more than the sum)
+  const bool overlap_reduce = kOverlapReduce && !timer && (nfloats & 3u) == 0 && total >= c->overlap_min_samples;
+  bool reduce_split = false;
   LaunchTimer lt(c, st, timer);
   uint64_t launches = 0, iterations = 0;
 
@@ -577,6 +602,17 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
   while (true) {
     if (left_upper == 0 && active_upper == 0) break;
     if (left_upper == 0 && active_upper <= c->finish_paths) {
+      if (overlap_reduce) {
+        // Most of the ordered sum runs on the side stream while the last paths run to their ends.
+        rtx::k_mark_unfinished<<<dim3(div_up(seg_max_upper, 64), nseg), 64, 0, st>>>(queue_of(c, cur), seg, cur, cap,
+                                                                                   c->res.p, prp);
+        HIP_TRY(hipEventRecord(c->ev_fork, st));
+        HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+        rtx::k_reduce_head<<<div_up(nfloats / 4, 256), 256, 0, c->side>>>(c->res.p, accum_band, c->stop4.p, nfloats, spp);
+        HIP_TRY(hipEventRecord(c->ev_join, c->side));
+        launches += 2;
+        reduce_split = true;
+      }
       lt.begin(kFinish, active_upper);
       RTX_BY_MODE(c->trace_mode, rtx::k_finish, kFinishBlock,
                   (dim3(div_up(seg_max_upper, kFinishBlock), nseg), kFinishBlock, lds_fin, st),
@@ -673,9 +709,13 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
   }
   (void)finished;
   // Fold the chunk's samples into the sums, in sample order.
-  const uint32_t nfloats = rp.band_pixels * 3;
   lt.begin(kReduce, total);
-  rtx::k_reduce<<<div_up(nfloats, 256), 256, 0, st>>>(c->res.p, accum_band, nfloats, spp);
+  if (reduce_split) {
+    HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
+    rtx::k_reduce_tail<<<div_up(nfloats / 4, 256), 256, 0, st>>>(c->res.p, accum_band, c->stop4.p, nfloats, spp);
+  } else {
+    rtx::k_reduce<<<div_up(nfloats, 256), 256, 0, st>>>(c->res.p, accum_band, nfloats, spp);
+  }
   lt.end();
   launches++;
   HIP_TRY(hipMemcpyAsync(&c->h_sum[0], sum, sizeof(rtx::Summary), hipMemcpyDeviceToHost, st));

@@ -208,6 +208,28 @@ def test_uploaded_sums_resume_a_render(rtx_lib):
     assert np.array_equal(got.view(np.uint32), whole.view(np.uint32))
 
 
+@pytest.mark.parametrize("finish_paths", [0, 4096, 1 << 20])
+def test_sum_beside_the_drain_kernel_keeps_the_bits(finish_paths, rtx_lib, monkeypatch):
+    """Large chunks add up most of their samples on a second stream while the drain kernel runs the
+    last paths (marker in the unfinished result slots, the rest added afterwards).  Forced on for
+    small renders and switched off, the sums are the same bits, whether the drain kernel takes over
+    as soon as the samples are exhausted or only for the last 4096 paths."""
+    for sc, sky in [(scenes.sphere_sky(glass=True), 1), (scenes.cornell(), 0), (scenes.soup(3000, 2, seed=9), 1)]:
+        out = []
+        for threshold in ("1", "18446744073709551615"):
+            monkeypatch.setenv("RTX_OVERLAP_MIN_SAMPLES", threshold)
+            kw = dict(width=128, height=96, sky=sky, pool_paths=1 << 14, finish_paths=finish_paths)
+            img, st, _ = gpu_render(Config(**kw), sc, 12, calls=[dict(spp=7), dict(spp=5, sample_base=7)])
+            band, _, _ = gpu_render(Config(**kw), sc, 6, calls=[dict(spp=6, row0=8, row1=40)])
+            out.append((img, band, st.bounces, st.launches))
+        monkeypatch.delenv("RTX_OVERLAP_MIN_SAMPLES")
+        assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+        assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+        assert out[0][2] == out[1][2]
+        if finish_paths != 0:
+            assert out[0][3] > out[1][3]       # the split sum really ran (two more launches per chunk)
+
+
 def test_result_buffer_chunking(rtx_lib):
     """A result buffer smaller than the call's samples: the call is rendered in chunks."""
     sc = scenes.cornell()
