@@ -1721,7 +1721,8 @@ __global__ __launch_bounds__(256) void k_reduce_tail(const float* res, float* ac
   if (first >= spp_chunk) return;
   float4 acc = reinterpret_cast<const float4*>(accum)[f];
   const float4* src = reinterpret_cast<const float4*>(res) + f;
-  for (uint32_t s = first; s < spp_chunk; s++) {
+#pragma unroll 8
+  for (uint32_t s = first; s < spp_chunk; s++) {  // (few lanes get here; their loads should overlap)
     float4 v = src[(size_t)s * n4];
     if (s >= stop.x) acc.x += v.x;
     if (s >= stop.y) acc.y += v.y;
