@@ -767,15 +767,38 @@ __device__ __forceinline__ bool occluded(const SceneDev& sc, const Geom& g, f3 o
 // Surface normal and material of a hit (reference Scene.h:169-171,181-187;
 // Sphere::normal Obj.h:269-271).  The mesh normal is normalize(Ng) with
 // Ng = (b-a)x(c-a), not flipped towards the ray.
+// The sphere a lane hit last, kept by kernels that run a path for many bounces: a path caught
+// inside a glass sphere hits that sphere every time, and its three loads would stand in the
+// chain of every bounce.
+struct LastSphere {
+  uint32_t index = 0xffffffffu;
+  float4 centre_radius, material;
+  int surface;
+};
 __device__ __forceinline__ void hit_surface(const SceneDev& sc, const Geom& g, uint32_t id, f3 o, f3 d, float t,
-                                            f3& n, f3& albedo, float& emission, int& surface) {
+                                            f3& n, f3& albedo, float& emission, int& surface,
+                                            LastSphere* last = nullptr) {
   if (id & kSphereBit) {
     uint32_t i = id & ~kSphereBit;
-    float4 m = sc.sph1[i];
     f3 p = vadd(o, vscale(d, t));
+    if (last && last->index == i) {
+      const float4 s = last->centre_radius, m = last->material;
+      n = vdivs(vsub(p, mk3(s.x, s.y, s.z)), s.w);
+      albedo = mk3(m.x, m.y, m.z);
+      emission = m.w;
+      surface = last->surface;
+      return;
+    }
+    float4 m = sc.sph1[i];
     if (i < sc.num_spheres) {
       float4 s = sc.sph0[i];
       n = vdivs(vsub(p, mk3(s.x, s.y, s.z)), s.w);
+      if (last) {
+        last->index = i;
+        last->centre_radius = s;
+        last->material = m;
+        last->surface = sc.sph2[i];
+      }
     } else if (i < sc.num_spheres + sc.num_boxes) {
       float4 a = sc.box0[i - sc.num_spheres], b = sc.box1[i - sc.num_spheres];
       n = box_normal(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), p);
@@ -1001,7 +1024,8 @@ __device__ __forceinline__ void store_path(const SceneDev& sc, const Queue& q, u
 // the next ray); `want_shadow` asks for the NEE segment in `sr` to be tested for
 // occlusion before its contribution is added to the path's colour.
 __device__ __forceinline__ bool shade_bounce(const SceneDev& sc, const Geom& g, PathState& p, float t,
-                                             uint32_t id, bool& want_shadow, bool& did_nee, ShadowReq& sr) {
+                                             uint32_t id, bool& want_shadow, bool& did_nee, ShadowReq& sr,
+                                             LastSphere* last = nullptr) {
   want_shadow = false;
   did_nee = false;
   if (sc.max_bounces) p.depth++;
@@ -1015,7 +1039,7 @@ __device__ __forceinline__ bool shade_bounce(const SceneDev& sc, const Geom& g, 
   f3 n3, albedo;
   float emis;
   int surface;
-  hit_surface(sc, g, id, p.o, p.d, t, n3, albedo, emis, surface);
+  hit_surface(sc, g, id, p.o, p.d, t, n3, albedo, emis, surface, last);
   if (sc.integrator == 1) {  // rayTraceNormals, Integrator.h:87-96
     p.col = vadd(vscale(n3, 0.5f), splat3(0.5f));
     return false;
@@ -1595,6 +1619,7 @@ __global__ __launch_bounds__(BLOCK) void k_finish(SceneDev sc, Queue q, const Se
     PathState p;
     load_path(sc, q, s * cap + j, j >= seg[s].gen_slot0, *prp,
               (uint32_t)seg[s].gen_ordinal0 + (j - seg[s].gen_slot0), p);
+    LastSphere last;
     for (uint32_t it = 0; it < kFinishCap; it++) {
       float t;
       uint32_t id;
@@ -1602,7 +1627,7 @@ __global__ __launch_bounds__(BLOCK) void k_finish(SceneDev sc, Queue q, const Se
       nb++;
       bool want_shadow, did_nee;
       ShadowReq sr;
-      bool alive = shade_bounce(sc, geom, p, t, id, want_shadow, did_nee, sr);
+      bool alive = shade_bounce(sc, geom, p, t, id, want_shadow, did_nee, sr, &last);
       nn += did_nee ? 1u : 0u;
       if (want_shadow) {
         ns++;
