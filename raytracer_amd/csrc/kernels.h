@@ -62,6 +62,7 @@ struct SceneDev {
   const float4* sph0;    // per sphere: (c.xyz, r)
   const float4* sph1;    // per analytic object: (albedo.rgb, emission)
   const int* sph2;       //                      surface
+  const int* sph3;       // per sphere: 1 = no triangle comes near its ball (LastSphere::clear)
   const float4* box0;    // per box: (min.xyz, 0)
   const float4* box1;    //          (max.xyz, 0)
   const float4* pln0;    // per plane: (point.xyz, 0)
@@ -680,6 +681,17 @@ __device__ __forceinline__ bool mesh_any(const SceneDev& sc, const Geom& g, f3 o
   }
 }
 
+// The sphere a lane hit last, kept by kernels that run a path for many bounces: a path caught
+// inside a glass sphere hits that sphere every time, and its three loads would stand in the
+// chain of every bounce.
+// `clear` (from the host): no triangle's box comes within a thousandth of a radius of the
+// sphere's box.  A ray that starts inside such a sphere and ends on it cannot meet a triangle
+// on the way, so cast_ray skips the mesh for it.
+struct LastSphere {
+  uint32_t index = 0xffffffffu;
+  float4 centre_radius, material;
+  int surface, clear = 0;
+};
 // The analytic objects of Scene::castRay (reference Scene.h:164-188): spheres in
 // order, then boxes and planes continuing the same list (t > EPS, the first of
 // equal t wins); the winner replaces the mesh hit only when strictly closer.
@@ -744,10 +756,20 @@ __device__ __forceinline__ bool analytic_any(const SceneDev& sc, f3 o, f3 d, flo
 // kSphereBit|index, or triangle slot.
 template <int MODE>
 __device__ __forceinline__ void cast_ray(const SceneDev& sc, const Geom& g, f3 o, f3 d, const Stack& stk,
-                                         float& t_out, uint32_t& id_out) {
+                                         float& t_out, uint32_t& id_out, const LastSphere* last = nullptr) {
   float ts = INFINITY;
   uint32_t sid = kMiss;
   analytic_closest(sc, o, d, ts, sid);
+  if (last && last->clear && sid != kMiss && sid == (kSphereBit | last->index)) {
+    // From inside the sphere hit last to that sphere again (the inside of a glass ball): the whole
+    // segment lies in the ball, give or take a rounding, and no triangle comes that near.
+    const float4 s = last->centre_radius;
+    if (vsqrnorm(vsub(o, mk3(s.x, s.y, s.z))) <= s.w * s.w * 1.0002f) {
+      t_out = ts;
+      id_out = sid;
+      return;
+    }
+  }
   float t;
   uint32_t slot;
   mesh_closest<MODE>(sc, g, o, d, stk, ts, t, slot);
@@ -767,14 +789,6 @@ __device__ __forceinline__ bool occluded(const SceneDev& sc, const Geom& g, f3 o
 // Surface normal and material of a hit (reference Scene.h:169-171,181-187;
 // Sphere::normal Obj.h:269-271).  The mesh normal is normalize(Ng) with
 // Ng = (b-a)x(c-a), not flipped towards the ray.
-// The sphere a lane hit last, kept by kernels that run a path for many bounces: a path caught
-// inside a glass sphere hits that sphere every time, and its three loads would stand in the
-// chain of every bounce.
-struct LastSphere {
-  uint32_t index = 0xffffffffu;
-  float4 centre_radius, material;
-  int surface;
-};
 __device__ __forceinline__ void hit_surface(const SceneDev& sc, const Geom& g, uint32_t id, f3 o, f3 d, float t,
                                             f3& n, f3& albedo, float& emission, int& surface,
                                             LastSphere* last = nullptr) {
@@ -798,6 +812,7 @@ __device__ __forceinline__ void hit_surface(const SceneDev& sc, const Geom& g, u
         last->centre_radius = s;
         last->material = m;
         last->surface = sc.sph2[i];
+        last->clear = sc.sph3[i];
       }
     } else if (i < sc.num_spheres + sc.num_boxes) {
       float4 a = sc.box0[i - sc.num_spheres], b = sc.box1[i - sc.num_spheres];
@@ -1623,7 +1638,7 @@ __global__ __launch_bounds__(BLOCK) void k_finish(SceneDev sc, Queue q, const Se
     for (uint32_t it = 0; it < kFinishCap; it++) {
       float t;
       uint32_t id;
-      cast_ray<MODE>(sc, geom, p.o, p.d, stk, t, id);
+      cast_ray<MODE>(sc, geom, p.o, p.d, stk, t, id, &last);
       nb++;
       bool want_shadow, did_nee;
       ShadowReq sr;

@@ -98,7 +98,7 @@ struct rtx_ctx {
   // scene
   bool have_scene = false;
   DevBuf<float4> nodes, tris, mat0, sph0, sph1, box0, box1, pln0, pln1, light0, light1, light2, light3;
-  DevBuf<int> mat1, sph2;
+  DevBuf<int> mat1, sph2, sph3;
   rtx::SceneDev scene{};
   rtx_scene_info info{};
   int stack_entries = 8;    // stack entries per lane kept in LDS
@@ -169,7 +169,7 @@ void free_ctx(rtx_ctx* c) {
   if (!c) return;
   DeviceGuard g(c->device);
   c->nodes.release(); c->tris.release();
-  c->mat0.release(); c->mat1.release(); c->sph0.release(); c->sph1.release(); c->sph2.release();
+  c->mat0.release(); c->mat1.release(); c->sph0.release(); c->sph1.release(); c->sph2.release(); c->sph3.release();
   c->box0.release(); c->box1.release(); c->pln0.release(); c->pln1.release();
   c->light0.release(); c->light1.release(); c->light2.release(); c->light3.release();
   for (int i = 0; i < 2; i++) {
@@ -388,6 +388,33 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
     pl1[i] = make_float4(q.normal[0], q.normal[1], q.normal[2], 0.f);
     put_material(s->num_spheres + s->num_boxes + i, q.material);
   }
+  // Spheres no triangle comes near (LastSphere::clear): every triangle's box stays outside the
+  // sphere's box grown by a thousandth of the radius (and a little more for large coordinates).
+  std::vector<int> sp3(s->num_spheres, 0);
+  if ((double)s->num_spheres * (double)nt <= 1.0e8) {
+    for (size_t i = 0; i < s->num_spheres; i++) {
+      const rtx_sphere& q = s->spheres[i];
+      if (!(q.r > 0.0f) || !std::isfinite(q.r)) continue;
+      float lo[3], hi[3];
+      bool clear = true;
+      for (int k = 0; k < 3; k++) {
+        const float grow = q.r * 1.001f + 1.0e-5f * (std::fabs(q.c[k]) + q.r) + 1.0e-30f;
+        lo[k] = q.c[k] - grow;
+        hi[k] = q.c[k] + grow;
+        clear = clear && std::isfinite(lo[k]) && std::isfinite(hi[k]);
+      }
+      for (size_t t = 0; clear && t < nt; t++) {
+        const float* p = s->triangles + 9 * t;
+        bool apart = false;
+        for (int k = 0; k < 3; k++) {
+          const float tlo = std::min(p[k], std::min(p[3 + k], p[6 + k])), thi = std::max(p[k], std::max(p[3 + k], p[6 + k]));
+          if (thi < lo[k] || tlo > hi[k]) apart = true;   // (a NaN coordinate compares false: not apart)
+        }
+        clear = apart;
+      }
+      sp3[i] = clear ? 1 : 0;
+    }
+  }
   // Light list, Scene::commit (Scene.h:129-141): triangles in order whose material
   // emission exceeds the threshold; per light the Triangle ctor's n and rcp_area
   // (Obj.h:107): n = normalize((b-a)x(c-b)), rcp_area = 2/|(b-a)x(c-b)|.
@@ -415,6 +442,7 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
   HIP_TRY(c->sph0.upload(sp0));
   HIP_TRY(c->sph1.upload(sp1));
   HIP_TRY(c->sph2.upload(sp2));
+  HIP_TRY(c->sph3.upload(sp3));
   HIP_TRY(c->box0.upload(bx0));
   HIP_TRY(c->box1.upload(bx1));
   HIP_TRY(c->pln0.upload(pl0));
@@ -427,7 +455,7 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
   rtx::SceneDev& d = c->scene;
   d.nodes = c->nodes.p; d.tris = c->tris.p;
   d.mat0 = c->mat0.p; d.mat1 = c->mat1.p;
-  d.sph0 = c->sph0.p; d.sph1 = c->sph1.p; d.sph2 = c->sph2.p;
+  d.sph0 = c->sph0.p; d.sph1 = c->sph1.p; d.sph2 = c->sph2.p; d.sph3 = c->sph3.p;
   d.box0 = c->box0.p; d.box1 = c->box1.p; d.pln0 = c->pln0.p; d.pln1 = c->pln1.p;
   d.num_boxes = (uint32_t)s->num_boxes;
   d.num_planes = (uint32_t)s->num_planes;

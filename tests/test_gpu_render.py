@@ -230,6 +230,29 @@ def test_sum_beside_the_drain_kernel_keeps_the_bits(finish_paths, rtx_lib, monke
             assert out[0][3] > out[1][3]       # the split sum really ran (two more launches per chunk)
 
 
+@pytest.mark.parametrize("inside", [True, False], ids=["triangle_inside_sphere", "triangle_far_away"])
+def test_drain_kernel_shortcut_inside_spheres(inside, oracle, rtx_lib):
+    """The drain kernel skips the mesh for a ray that runs from inside a sphere to that sphere again
+    when the host found no triangle near the sphere.  A small bright triangle INSIDE the glass sphere
+    must switch the shortcut off (its light would be lost otherwise); with the triangle far away the
+    shortcut is on.  Every path runs in the drain kernel (finish_paths above the sample count); the
+    image must follow the oracle either way."""
+    sc0 = scenes.sphere_sky(glass=True)
+    c = np.array([0.0, 1.0, -1.0]) if inside else np.array([0.0, 5.0, -1.0])
+    tri = np.concatenate([c + [-0.2, -0.1, 0.0], c + [0.2, -0.1, 0.05], c + [0.0, 0.25, -0.05]]).astype(np.float32)
+    mats = np.concatenate([sc0.materials, np.array([scenes.material((1, 1, 1), 40.0)], scenes.MATERIAL_DTYPE)])
+    sc = scenes.SceneData(np.concatenate([sc0.triangles, tri[None]]), np.concatenate([sc0.material_index, [len(mats) - 1]]),
+                          mats, sc0.spheres, name="lamp_in_glass")
+    cfg = Config(width=96, height=96, sky=0, pool_paths=1 << 17, finish_paths=1 << 20, nee_threshold=1000.0)
+    want, ost = oracle.OracleScene(sc, cfg).render(8)
+    got, st, info = gpu_render(cfg, sc, 8)
+    assert info.num_lights == 0 and st.paths == ost.paths
+    assert close_fraction(got, want) >= 0.98
+    assert abs(luminance(got) - luminance(want)) <= 0.02 * luminance(want) + 1e-4
+    if inside:
+        assert luminance(want) > 0.05      # the lamp is seen through the glass: losing it would show
+
+
 def test_result_buffer_chunking(rtx_lib):
     """A result buffer smaller than the call's samples: the call is rendered in chunks."""
     sc = scenes.cornell()
