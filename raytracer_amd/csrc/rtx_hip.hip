@@ -54,6 +54,10 @@ constexpr int kFinishBlock = 64;
 #endif
 constexpr bool kOverlapReduce = RTX_OVERLAP_REDUCE != 0;
 constexpr unsigned long long kOverlapMinSamples = 1ull << 26;
+#ifndef RTX_TIGHT_END
+#define RTX_TIGHT_END 1
+#endif
+constexpr bool kTightEnd = RTX_TIGHT_END != 0;
 constexpr size_t kFusedSmallSceneBytes = 4096;  // k_trace_shade: scenes up to this size run 128-thread blocks
 constexpr uint32_t kTraceBatches = 2;  // ray batches per block of k_intersect/k_shadow (the next batch's loads overlap the current traversal)
 constexpr int kPollSlots = 4;
@@ -618,13 +622,33 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
   int poll_head = 0, poll_pending = 0;
   uint64_t since_poll = 0;
   bool finished = false;
+  // Towards the end of the samples the host stops running far ahead of the device: rounds
+  // enqueued on stale knowledge keep their full grids and go on after the paths are gone.  It
+  // follows how fast the samples go (from consecutive snapshots) and, once they are about to run
+  // out at the round it is enqueuing, takes a snapshot every round and waits for the one before.
+  uint64_t snap_round[kPollSlots] = {};
+  uint64_t known_round = 0, prev_round = 0;
+  unsigned long long known_left = left_upper, prev_next = first, rate = 0;
+  bool have_prev = false;
 
-  auto absorb = [&](const rtx::Summary& h) {
+  auto absorb = [&](const rtx::Summary& h, uint64_t round) {
     left_upper = h.total_samples - h.next_sample;
     if (left_upper == 0) {
       seg_max_upper = std::min(seg_max_upper, h.active_max);
       active_upper = std::min(active_upper, h.active_total);
     }
+    if (have_prev && round > prev_round && h.next_sample >= prev_next)
+      rate = std::max(rate, (h.next_sample - prev_next) / (round - prev_round));
+    have_prev = true;
+    prev_round = round;
+    prev_next = h.next_sample;
+    known_round = round;
+    known_left = left_upper;
+  };
+  auto near_the_end = [&]() {
+    if (known_left == 0 || total <= 4ull * pool) return true;
+    if (rate == 0) return false;
+    return known_left <= rate * ((iterations - known_round) + 3);
   };
 
   while (true) {
@@ -714,24 +738,27 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
     since_poll++;
     cur = nxt;
 
-    const uint64_t poll_every = left_upper > 0 ? 4 : 2;
+    const bool tight = kTightEnd && near_the_end();
+    const uint64_t poll_every = tight ? 1 : 4;
     if (since_poll >= poll_every) {
       since_poll = 0;
-      if (poll_pending == kPollSlots - 1) {  // ring full: wait for the oldest snapshot
+      const int max_pending = tight ? 1 : kPollSlots - 1;
+      while (poll_pending >= max_pending) {  // wait for the oldest snapshot
         int slot = (poll_head - poll_pending + 2 * kPollSlots) % kPollSlots;
         HIP_TRY(hipEventSynchronize(c->poll_ev[slot]));
-        absorb(c->h_sum[slot]);
+        absorb(c->h_sum[slot], snap_round[slot]);
         poll_pending--;
       }
       HIP_TRY(hipMemcpyAsync(&c->h_sum[poll_head], sum, sizeof(rtx::Summary), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipEventRecord(c->poll_ev[poll_head], st));
+      snap_round[poll_head] = iterations;
       poll_head = (poll_head + 1) % kPollSlots;
       poll_pending++;
     }
     while (poll_pending > 0) {  // take every snapshot that has already landed
       int slot = (poll_head - poll_pending + 2 * kPollSlots) % kPollSlots;
       if (hipEventQuery(c->poll_ev[slot]) != hipSuccess) break;
-      absorb(c->h_sum[slot]);
+      absorb(c->h_sum[slot], snap_round[slot]);
       poll_pending--;
     }
   }
