@@ -1192,9 +1192,11 @@ __global__ void k_begin(SegCounter* seg, Summary* sum, uint32_t nseg, unsigned l
 // out), publishes the new fills, clears qd's counters and updates the summary.
 __global__ __launch_bounds__(1024) void k_plan(SegCounter* seg, Summary* sum, int qf, int qd,
                                                uint32_t nseg, uint32_t cap) {
-  __shared__ unsigned long long scan[1024];
-  __shared__ uint32_t red[5][1024];
-  const uint32_t s = threadIdx.x;
+  // blockDim.x is a multiple of 64 that covers nseg.  Scans and sums go through the lanes of a
+  // wave with shuffles and across the (at most 16) waves through LDS: three barriers in all.
+  __shared__ unsigned long long wave_room[16];
+  __shared__ uint32_t wave_part[16][5];
+  const uint32_t s = threadIdx.x, lane = s & 63u, wave = s >> 6, nwaves = blockDim.x >> 6;
   uint32_t n = 0, sh = 0, ne = 0, drained = 0, room = 0;
   if (s < nseg) {
     unsigned long long c = seg[s].c[qf];
@@ -1204,18 +1206,22 @@ __global__ __launch_bounds__(1024) void k_plan(SegCounter* seg, Summary* sum, in
     room = cap - n;
     if (qd >= 0) drained = seg_paths(seg[s].c[qd]);
   }
-  scan[s] = room;
+  // inclusive scan of the room within the wave
+  unsigned long long incl = room;
+  for (int off = 1; off < 64; off <<= 1) {
+    const unsigned long long up = __shfl_up(incl, off, 64);
+    if ((int)lane >= off) incl += up;
+  }
+  if (lane == 63) wave_room[wave] = incl;
   __syncthreads();
-  for (uint32_t off = 1; off < 1024; off <<= 1) {  // inclusive Hillis-Steele scan
-    unsigned long long v = scan[s];
-    if (s >= off) v += scan[s - off];
-    __syncthreads();
-    scan[s] = v;
-    __syncthreads();
+  unsigned long long before_wave = 0, room_total = 0;
+  for (uint32_t w = 0; w < nwaves; w++) {
+    if (w < wave) before_wave += wave_room[w];
+    room_total += wave_room[w];
   }
   const unsigned long long next = sum->next_sample, total = sum->total_samples;
   const unsigned long long left = total - next;
-  const unsigned long long before_room = scan[s] - room;
+  const unsigned long long before_room = before_wave + incl - room;
   const unsigned long long before = before_room < left ? before_room : left;
   const unsigned long long can = left - before;
   const uint32_t g = (uint32_t)(can < room ? can : room);
@@ -1226,33 +1232,41 @@ __global__ __launch_bounds__(1024) void k_plan(SegCounter* seg, Summary* sum, in
     seg[s].c[qf] = (unsigned long long)(n + g);
     if (qd >= 0) seg[s].c[qd] = 0;
   }
-  red[0][s] = g;
-  red[1][s] = n + g;
-  red[2][s] = sh;
-  red[3][s] = ne;
-  red[4][s] = drained;
-  __syncthreads();
-  for (uint32_t off = 512; off > 0; off >>= 1) {
-    if (s < off) {
-      red[0][s] += red[0][s + off];
-      red[1][s] = red[1][s] > red[1][s + off] ? red[1][s] : red[1][s + off];
-      red[2][s] += red[2][s + off];
-      red[3][s] += red[3][s + off];
-      red[4][s] += red[4][s + off];
-    }
-    __syncthreads();
+  // sums of g, shadow rays, light samples and drained paths; maximum of n + g
+  uint32_t v0 = g, v1 = n + g, v2 = sh, v3 = ne, v4 = drained;
+  for (int off = 32; off > 0; off >>= 1) {
+    v0 += __shfl_down(v0, off, 64);
+    const uint32_t o1 = __shfl_down(v1, off, 64);
+    v1 = v1 > o1 ? v1 : o1;
+    v2 += __shfl_down(v2, off, 64);
+    v3 += __shfl_down(v3, off, 64);
+    v4 += __shfl_down(v4, off, 64);
   }
-  // active_total needs the sum of n+g, not the max: recompute from the scan.
+  if (lane == 0) {
+    wave_part[wave][0] = v0;
+    wave_part[wave][1] = v1;
+    wave_part[wave][2] = v2;
+    wave_part[wave][3] = v3;
+    wave_part[wave][4] = v4;
+  }
+  __syncthreads();
   if (s == 0) {
-    const unsigned long long room_total = scan[1023];
-    const unsigned long long gen_total = red[0][0];
+    unsigned long long gen_total = 0, shadow_total = 0, nee_total = 0, drained_total = 0;
+    uint32_t fill_max = 0;
+    for (uint32_t w = 0; w < nwaves; w++) {
+      gen_total += wave_part[w][0];
+      fill_max = fill_max > wave_part[w][1] ? fill_max : wave_part[w][1];
+      shadow_total += wave_part[w][2];
+      nee_total += wave_part[w][3];
+      drained_total += wave_part[w][4];
+    }
     sum->next_sample = next + gen_total;
     sum->stat_paths += gen_total;
-    sum->stat_bounces += red[4][0];
-    sum->stat_shadow += red[2][0];
-    sum->stat_nee += red[3][0];
+    sum->stat_bounces += drained_total;
+    sum->stat_shadow += shadow_total;
+    sum->stat_nee += nee_total;
     sum->active_total = (uint32_t)((unsigned long long)nseg * cap - room_total + gen_total);
-    sum->active_max = red[1][0];
+    sum->active_max = fill_max;
   }
 }
 

@@ -594,6 +594,7 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
   // (and not for small chunks: the extra launches and events cost more than the sum)
   const bool overlap_reduce = kOverlapReduce && !timer && (nfloats & 3u) == 0 && total >= c->overlap_min_samples;
   bool reduce_split = false;
+  const uint32_t plan_threads = (nseg + 63u) / 64u * 64u;  // k_plan: one thread per segment, whole waves
   LaunchTimer lt(c, st, timer);
   uint64_t launches = 0, iterations = 0;
 
@@ -603,7 +604,7 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
   pr.recompute = c->cfg.primary_rays != 1 && c->trace_mode != rtx::kGlobalBvh4 && c->cfg.camera != 1;
   const rtx::Primary* prp = c->primary.p;
   rtx::k_begin<<<div_up(nseg, 256), 256, 0, st>>>(seg, sum, nseg, total, pr, c->primary.p);
-  rtx::k_plan<<<1, 1024, 0, st>>>(seg, sum, 0, -1, nseg, cap);
+  rtx::k_plan<<<1, plan_threads, 0, st>>>(seg, sum, 0, -1, nseg, cap);
   const uint32_t first = (uint32_t)std::min<unsigned long long>(total, pool);
   launches += 2;
   if (!pr.recompute) {
@@ -722,7 +723,7 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
       lt.end();
       launches++;
     }
-    rtx::k_plan<<<1, 1024, 0, st>>>(seg, sum, nxt, cur, nseg, cap);
+    rtx::k_plan<<<1, plan_threads, 0, st>>>(seg, sum, nxt, cur, nseg, cap);
     launches++;
     if (left_upper > 0) {
       if (!pr.recompute) {
