@@ -147,6 +147,13 @@ typedef struct {
   double ms_generate, ms_intersect, ms_shade, ms_shadow, ms_finish, ms_reduce, ms_other;
   uint64_t timed_launches_intersect, timed_launches_shade, timed_launches_shadow,
       timed_launches_generate;
+  uint64_t nan_paths;        /* finished paths whose colour holds a NaN or an infinity.  The reference can
+                                produce them (sqrt of a slightly negative number, Integrator.h:24) and paints
+                                them magenta under RT_DEBUG (Raytracer.cpp:259-264); they are counted here,
+                                not masked: such a sample goes into the sum as it is */
+  uint64_t truncated_paths;  /* paths the drain kernel gave up on after 65536 bounces (the reference's loop
+                                has no bound, Integrator.h:108; at rr_cap 0.99 such a path has probability
+                                below 1e-286); their colour so far is stored as if they had ended */
 } rtx_stats;
 
 typedef struct {
@@ -205,6 +212,13 @@ int rtx_trace_closest(rtx_ctx* ctx, const float* rays_host, size_t n, uint32_t* 
 /* Scene::isOccluded (Scene.h:191-225) for n segments: occluded_out[i] in {0,1}. */
 int rtx_trace_occluded(rtx_ctx* ctx, const float* rays_host, const float* distance_host, size_t n,
                        uint8_t* occluded_out);
+
+/* Known-answer hook for the device's generator (class Pcg, Sampler.h:11-42), all outputs host
+ * arrays of n elements, any of them may be NULL: rand_out[i] = the i-th rand_pcg() of Pcg(seed),
+ * uniform_out[i] = the i-th Uniform() of another Pcg(seed), hash_out[i] = pcg_hash(seed + i),
+ * each computed by the device functions the render kernels use.  n <= 2^20.  Synchronous. */
+int rtx_debug_pcg(rtx_ctx* ctx, uint32_t seed, uint32_t n, uint32_t* rand_out, float* uniform_out,
+                  uint32_t* hash_out);
 
 /* Counters since rtx_create or the last rtx_reset_stats. */
 int rtx_get_stats(rtx_ctx* ctx, rtx_stats* out);

@@ -75,6 +75,7 @@ class Stats(C.Structure):
         ("ms_other", C.c_double),
         ("timed_launches_intersect", C.c_uint64), ("timed_launches_shade", C.c_uint64),
         ("timed_launches_shadow", C.c_uint64), ("timed_launches_generate", C.c_uint64),
+        ("nan_paths", C.c_uint64), ("truncated_paths", C.c_uint64),
     ]
 
     def as_dict(self) -> dict:
@@ -94,7 +95,7 @@ SYMBOLS = [
     "rtx_last_error", "rtx_create", "rtx_destroy", "rtx_set_scene", "rtx_get_scene_info",
     "rtx_render", "rtx_resolve", "rtx_trace_closest", "rtx_trace_occluded", "rtx_get_stats",
     "rtx_reset_stats", "rtx_set_profiling", "rtx_accum_alloc", "rtx_accum_free", "rtx_accum_clear",
-    "rtx_accum_upload",
+    "rtx_accum_upload", "rtx_debug_pcg",
 ]
 
 _lib = None
@@ -131,6 +132,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rtx_accum_free.argtypes = [vp, vp]
     lib.rtx_accum_clear.argtypes = [vp, vp, vp]
     lib.rtx_accum_upload.argtypes = [vp, vp, vp, vp]
+    lib.rtx_debug_pcg.argtypes = [vp, u32, u32, vp, vp, vp]
     if path is None:
         _lib = lib
     return lib
@@ -324,6 +326,12 @@ class Renderer:
         self._check(self.lib.rtx_trace_occluded(self._ctx, _ptr(rays), _ptr(dist), rays.shape[0],
                                                 _ptr(out)))
         return out
+
+    def debug_pcg(self, seed: int, n: int):
+        """(rand_pcg draws, Uniform draws, pcg_hash(seed + i)) computed on the device."""
+        rnd, uni, hsh = np.empty(n, np.uint32), np.empty(n, np.float32), np.empty(n, np.uint32)
+        self._check(self.lib.rtx_debug_pcg(self._ctx, seed, n, _ptr(rnd), _ptr(uni), _ptr(hsh)))
+        return rnd, uni, hsh
 
     # -- statistics ------------------------------------------------------------------
     def stats(self) -> Stats:

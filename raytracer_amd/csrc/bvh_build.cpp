@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <new>
 #include <thread>
 
 namespace rtx {
@@ -356,19 +357,33 @@ void build_bvh(const float* tris, size_t ntri, uint32_t max_leaf, uint32_t width
   if (!b.deferred.empty()) {
     std::vector<std::vector<TmpNode>> sub(b.deferred.size());
     std::atomic<size_t> next_task{0};
-    auto work = [&]() {
-      for (size_t k; (k = next_task.fetch_add(1)) < b.deferred.size();) {
-        const Builder::Deferred& d = b.deferred[k];
-        Builder w(tb, cent, out.order, kMaxLeaf);
-        w.nodes.reserve(d.count);
-        w.build(d.first, d.count, d.depth);
-        sub[k] = std::move(w.nodes);
+    // A worker never lets an exception escape (that would end the process): it notes the
+    // failure and stops taking tasks; the calling thread rethrows after every worker is joined.
+    std::atomic<bool> failed{false};
+    auto work = [&]() noexcept {
+      try {
+        for (size_t k; !failed.load() && (k = next_task.fetch_add(1)) < b.deferred.size();) {
+          const Builder::Deferred& d = b.deferred[k];
+          Builder w(tb, cent, out.order, kMaxLeaf);
+          w.nodes.reserve(d.count);
+          w.build(d.first, d.count, d.depth);
+          sub[k] = std::move(w.nodes);
+        }
+      } catch (...) {
+        failed.store(true);
       }
     };
+    // Thread creation can be refused (a process limit): the workers that did start, and this
+    // thread, then share the tasks; the shared task counter makes any number of takers correct.
     std::vector<std::thread> pool;
-    for (uint32_t t = 1; t < workers; t++) pool.emplace_back(work);
+    try {
+      pool.reserve(workers);
+      for (uint32_t t = 1; t < workers; t++) pool.emplace_back(work);
+    } catch (...) {
+    }
     work();
     for (std::thread& t : pool) t.join();
+    if (failed.load()) throw std::bad_alloc();
     for (size_t k = 0; k < sub.size(); k++) {
       // local node 0 takes the placeholder's place, local node i > 0 goes to base + i - 1
       const int32_t base = (int32_t)b.nodes.size();

@@ -126,7 +126,8 @@ struct Summary {
   unsigned long long stat_paths, stat_bounces, stat_nee, stat_shadow;
   uint32_t active_total;  // paths in the queue about to be traced
   uint32_t active_max;    // the fullest segment
-  uint32_t pad[2];
+  uint32_t stat_nan;        // finished paths whose colour has a NaN or an infinity in it
+  uint32_t stat_truncated;  // paths k_finish gave up on at kFinishCap bounces
 };
 
 struct RenderParams {
@@ -1163,6 +1164,20 @@ __device__ __forceinline__ void store_result(float* res, uint32_t ordinal, f3 co
   dst[2] = col.z;
 }
 
+// Counts the finished paths whose colour is not finite (the reference can produce them:
+// sqrt of a slightly negative number at Integrator.h:24; they are counted, not masked).
+// Every lane of the wave calls this together; one atomic per wave that has any.
+__device__ __forceinline__ bool colour_not_finite(f3 c) {
+  return !(fabsf(c.x) < INFINITY && fabsf(c.y) < INFINITY && fabsf(c.z) < INFINITY);
+}
+__device__ __forceinline__ void wave_count(bool flag, uint32_t* counter) {
+  const unsigned long long m = __ballot(flag);
+  if (m != 0) {
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if (lane == (uint32_t)__builtin_ctzll(m)) atomicAdd(counter, (uint32_t)__popcll(m));
+  }
+}
+
 // ----------------------------------------------------------------------------
 // Kernels.
 
@@ -1183,6 +1198,8 @@ __global__ void k_begin(SegCounter* seg, Summary* sum, uint32_t nseg, unsigned l
     sum->stat_paths = sum->stat_bounces = sum->stat_nee = sum->stat_shadow = 0;
     sum->active_total = 0;
     sum->active_max = 0;
+    sum->stat_nan = 0;
+    sum->stat_truncated = 0;
   }
 }
 
@@ -1500,7 +1517,7 @@ __device__ __forceinline__ void block_append(bool alive, bool want_shadow, bool 
 // segment of `out`, finished paths store their colour to their sample's slot.
 __global__ __launch_bounds__(256) void k_shade_wave_append(SceneDev sc, Queue in, Queue out, ShadowQueue sq,
                                                const uint2* hits, SegCounter* seg, int qi, uint32_t cap,
-                                               float* res, const Primary* __restrict__ prp) {
+                                               float* res, const Primary* __restrict__ prp, Summary* sum) {
   const uint32_t s = blockIdx.y;
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n = seg_paths(seg[s].c[qi]);
@@ -1510,13 +1527,17 @@ __global__ __launch_bounds__(256) void k_shade_wave_append(SceneDev sc, Queue in
 
   PathState p;
   ShadowReq sr;
-  bool alive = false, want_shadow = false, did_nee = false;
+  bool alive = false, want_shadow = false, did_nee = false, bad = false;
   if (active) {
     load_path(sc, in, i, j >= seg[s].gen_slot0, *prp, (uint32_t)seg[s].gen_ordinal0 + (j - seg[s].gen_slot0), p);
     uint2 h = hits[i];
     alive = shade_bounce(sc, global_geom(sc), p, __uint_as_float(h.x), h.y, want_shadow, did_nee, sr);
-    if (!alive) store_result(res, p.ordinal, p.col);
+    if (!alive) {
+      store_result(res, p.ordinal, p.col);
+      bad = colour_not_finite(p.col);
+    }
   }
+  wave_count(bad, &sum->stat_nan);
   uint32_t pos, spos;
   wave_append(alive, want_shadow, did_nee, &seg[s].c[qi ^ 1], pos, spos);
   if (alive) store_path(sc, out, s * cap + pos, p);
@@ -1535,7 +1556,7 @@ __global__ __launch_bounds__(256) void k_shade_wave_append(SceneDev sc, Queue in
 template <int BLOCK, int MODE>
 __global__ __launch_bounds__(BLOCK) void k_trace_shade(SceneDev sc, Queue in, Queue out, ShadowQueue sq,
                                                        SegCounter* seg, int qi, uint32_t cap, float* res,
-                                                       TraceParams tp, const Primary* __restrict__ prp) {
+                                                       TraceParams tp, const Primary* __restrict__ prp, Summary* sum) {
   const uint32_t s = blockIdx.y;
   const uint32_t n = seg_paths(seg[s].c[qi]);
   if (blockIdx.x * BLOCK >= n) return;  // whole blocks beyond the fill leave; the rest stay for the barrier and the ballots
@@ -1546,15 +1567,19 @@ __global__ __launch_bounds__(BLOCK) void k_trace_shade(SceneDev sc, Queue in, Qu
 
   PathState p;
   ShadowReq sr;
-  bool alive = false, want_shadow = false, did_nee = false;
+  bool alive = false, want_shadow = false, did_nee = false, bad = false;
   if (active) {
     load_path(sc, in, i, j >= seg[s].gen_slot0, *prp, (uint32_t)seg[s].gen_ordinal0 + (j - seg[s].gen_slot0), p);
     float t;
     uint32_t id;
     cast_ray<MODE>(sc, geom, p.o, p.d, stk, t, id);
     alive = shade_bounce(sc, global_geom(sc), p, t, id, want_shadow, did_nee, sr);
-    if (!alive) store_result(res, p.ordinal, p.col);
+    if (!alive) {
+      store_result(res, p.ordinal, p.col);
+      bad = colour_not_finite(p.col);
+    }
   }
+  wave_count(bad, &sum->stat_nan);
   uint32_t pos, spos;  // (the per-block append of k_shade_block_append measured slower here)
   wave_append(alive, want_shadow, did_nee, &seg[s].c[qi ^ 1], pos, spos);
   if (alive) store_path(sc, out, s * cap + pos, p);
@@ -1571,7 +1596,8 @@ __global__ __launch_bounds__(BLOCK) void k_trace_shade(SceneDev sc, Queue in, Qu
 // streams, long runs), 2 % slower where most paths end at once (open scene, sky).
 __global__ __launch_bounds__(256) void k_shade_block_append(SceneDev sc, Queue in, Queue out, ShadowQueue sq,
                                                             const uint2* hits, SegCounter* seg, int qi,
-                                                            uint32_t cap, float* res, const Primary* __restrict__ prp) {
+                                                            uint32_t cap, float* res, const Primary* __restrict__ prp,
+                                                            Summary* sum) {
   const uint32_t s = blockIdx.y;
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n = seg_paths(seg[s].c[qi]);
@@ -1581,13 +1607,17 @@ __global__ __launch_bounds__(256) void k_shade_block_append(SceneDev sc, Queue i
 
   PathState p;
   ShadowReq sr;
-  bool alive = false, want_shadow = false, did_nee = false;
+  bool alive = false, want_shadow = false, did_nee = false, bad = false;
   if (active) {
     load_path(sc, in, i, j >= seg[s].gen_slot0, *prp, (uint32_t)seg[s].gen_ordinal0 + (j - seg[s].gen_slot0), p);
     uint2 h = hits[i];
     alive = shade_bounce(sc, global_geom(sc), p, __uint_as_float(h.x), h.y, want_shadow, did_nee, sr);
-    if (!alive) store_result(res, p.ordinal, p.col);
+    if (!alive) {
+      store_result(res, p.ordinal, p.col);
+      bad = colour_not_finite(p.col);
+    }
   }
+  wave_count(bad, &sum->stat_nan);
   uint32_t pos, spos;
   block_append(alive, want_shadow, did_nee, &seg[s].c[qi ^ 1], pos, spos);
   if (alive) store_path(sc, out, s * cap + pos, p);
@@ -1644,6 +1674,7 @@ __global__ __launch_bounds__(BLOCK) void k_finish(SceneDev sc, Queue q, const Se
   const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
   const bool active = j < seg_paths(seg[s].c[qi]);
   uint32_t nb = 0, nn = 0, ns = 0;
+  bool bad = false, truncated = false;
   if (active) {
     PathState p;
     load_path(sc, q, s * cap + j, j >= seg[s].gen_slot0, *prp,
@@ -1663,9 +1694,13 @@ __global__ __launch_bounds__(BLOCK) void k_finish(SceneDev sc, Queue q, const Se
         if (!occluded<MODE>(sc, geom, p.o, sr.d, sr.tfar, stk)) p.col = vadd(p.col, sr.contrib);
       }
       if (!alive) break;
+      truncated = it + 1 == kFinishCap;
     }
     store_result(res, p.ordinal, p.col);
+    bad = colour_not_finite(p.col);
   }
+  wave_count(bad, &sum->stat_nan);
+  wave_count(truncated, &sum->stat_truncated);
   // Statistics: one atomic per wave and counter (this kernel runs once per render).
   for (int off = 32; off > 0; off >>= 1) {
     nb += __shfl_down((int)nb, off, 64);
@@ -1849,6 +1884,20 @@ __global__ __launch_bounds__(BLOCK) void k_trace_occluded(SceneDev sc, const flo
   if (!(distance < 2.0f * sc.eps))  // Scene.h:192-194
     occ = occluded<MODE>(sc, geom, o, d, distance - sc.eps, stk);
   out[i] = occ ? 1 : 0;
+}
+
+// Device-side known-answer check of the generator (reference Sampler.h:24-41): thread 0 draws
+// n values of rand_pcg() from Pcg(seed), thread 1 n values of Uniform() from another Pcg(seed),
+// and thread 2 writes pcg_hash(seed + i).
+__global__ void k_debug_pcg(uint32_t seed, uint32_t n, uint32_t* rand_out, float* uniform_out, uint32_t* hash_out) {
+  const uint32_t which = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t state = seed;
+  if (which == 0 && rand_out)
+    for (uint32_t i = 0; i < n; i++) rand_out[i] = pcg_next(state);
+  if (which == 1 && uniform_out)
+    for (uint32_t i = 0; i < n; i++) uniform_out[i] = pcg_uniform(state);
+  if (which == 2 && hash_out)
+    for (uint32_t i = 0; i < n; i++) hash_out[i] = pcg_hash(seed + i);
 }
 
 __global__ void k_resolve(const float* accum, float* out, size_t n, float spp) {

@@ -33,6 +33,15 @@ int fail_hip(hipError_t e, const char* what) {
   return e == hipErrorOutOfMemory ? RTX_ERR_OUT_OF_MEMORY : RTX_ERR_HIP;
 }
 
+// For catch blocks: records the message if it can, never throws.
+int fail_nothrow(int code, const char* what, const char* detail) noexcept {
+  try {
+    g_last_error = std::string(what) + ": " + detail;
+  } catch (...) {
+  }
+  return code;
+}
+
 #define HIP_TRY(expr)                                  \
   do {                                                 \
     hipError_t e_ = (expr);                            \
@@ -66,11 +75,18 @@ template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  // n is the capacity the buffer really has: it stays 0 when the allocation fails, so a
+  // later "large enough already?" test cannot pass on a null pointer.
   hipError_t alloc(size_t count) {
     release();
-    n = count;
     if (count == 0) return hipSuccess;
-    return hipMalloc((void**)&p, count * sizeof(T));
+    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+    if (e != hipSuccess) {
+      p = nullptr;
+      return e;
+    }
+    n = count;
+    return hipSuccess;
   }
   hipError_t upload(const std::vector<T>& h) {
     hipError_t e = alloc(h.size());
@@ -199,7 +215,7 @@ extern "C" {
 
 const char* rtx_last_error(void) { return g_last_error.c_str(); }
 
-int rtx_create(const rtx_config* cfg, rtx_ctx** out) {
+static int impl_create(const rtx_config* cfg, rtx_ctx** out) {
   if (!cfg || !out) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_create: null argument");
   *out = nullptr;
   if (cfg->width == 0 || cfg->height == 0 || (uint64_t)cfg->width * cfg->height > (1ull << 30))
@@ -302,7 +318,7 @@ int rtx_create(const rtx_config* cfg, rtx_ctx** out) {
 
 void rtx_destroy(rtx_ctx* ctx) { free_ctx(ctx); }
 
-int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
+static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
   if (!c || !s) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_set_scene: null argument");
   if (s->num_triangles && (!s->triangles || !s->material_index || !s->materials))
     return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_set_scene: null geometry arrays");
@@ -438,6 +454,9 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
   }
 
   HIP_TRY(hipDeviceSynchronize());
+  // From here on the old scene's buffers are being replaced: until every upload has succeeded
+  // the context has no scene (a failure below must not leave renders running on freed memory).
+  c->have_scene = false;
   HIP_TRY(c->spill.alloc(spill_entries * (size_t)c->pool));
   HIP_TRY(c->nodes.upload(nodes));
   HIP_TRY(c->tris.upload(tr));
@@ -501,7 +520,7 @@ int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
   return RTX_OK;
 }
 
-int rtx_get_scene_info(rtx_ctx* c, rtx_scene_info* out) {
+static int impl_get_scene_info(rtx_ctx* c, rtx_scene_info* out) {
   if (!c || !out) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_get_scene_info: null argument");
   if (!c->have_scene) return fail(RTX_ERR_NO_SCENE, "rtx_get_scene_info: no scene set");
   *out = c->info;
@@ -690,10 +709,10 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
       lt.begin(kShade, active_upper);
       if (fused_block == 128)
         rtx::k_trace_shade<128, rtx::kLdsBvh2><<<dim3(div_up(seg_max_upper, 128), nseg), 128, lds_fused, st>>>(
-            c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp);
+            c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp, sum);
       else
         rtx::k_trace_shade<256, rtx::kLdsBvh2><<<dim3(div_up(seg_max_upper, 256), nseg), 256, lds_fused, st>>>(
-            c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp);
+            c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp, sum);
       lt.end();
       launches++;
     } else {
@@ -709,10 +728,10 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
     lt.begin(kShade, active_upper);
     if (shadows)
       rtx::k_shade_block_append<<<dim3(gx256, nseg), 256, 0, st>>>(c->scene, qc, qn, sq, c->hits.p, seg, cur, cap,
-                                                                  c->res.p, prp);
+                                                                  c->res.p, prp, sum);
     else
       rtx::k_shade_wave_append<<<dim3(gx256, nseg), 256, 0, st>>>(c->scene, qc, qn, sq, c->hits.p, seg, cur, cap,
-                                                                 c->res.p, prp);
+                                                                 c->res.p, prp, sum);
     lt.end();
     launches += 2;
     }
@@ -784,6 +803,8 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
   c->stats.bounces += h.stat_bounces;
   c->stats.nee_samples += h.stat_nee;
   c->stats.shadow_rays += h.stat_shadow;
+  c->stats.nan_paths += h.stat_nan;
+  c->stats.truncated_paths += h.stat_truncated;
   c->stats.iterations += iterations;
   c->stats.launches += launches;
   return RTX_OK;
@@ -793,7 +814,7 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
 
 extern "C" {
 
-int rtx_render(rtx_ctx* c, float* accum_dev, uint32_t spp, uint32_t sample_base, uint64_t seed,
+static int impl_render(rtx_ctx* c, float* accum_dev, uint32_t spp, uint32_t sample_base, uint64_t seed,
                const float cam_offset[3], uint32_t row0, uint32_t row1, void* stream) {
   if (!c || !accum_dev) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render: null argument");
   if (!c->have_scene) return fail(RTX_ERR_NO_SCENE, "rtx_render: no scene set");
@@ -888,7 +909,7 @@ int rtx_render(rtx_ctx* c, float* accum_dev, uint32_t spp, uint32_t sample_base,
   return rc;
 }
 
-int rtx_resolve(rtx_ctx* c, const float* accum_dev, uint32_t total_spp, float* rgb_out_host, void* stream) {
+static int impl_resolve(rtx_ctx* c, const float* accum_dev, uint32_t total_spp, float* rgb_out_host, void* stream) {
   if (!c || !accum_dev || !rgb_out_host) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_resolve: null argument");
   if (total_spp == 0) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_resolve: total_spp is 0");
   DeviceGuard g(c->device);
@@ -901,7 +922,7 @@ int rtx_resolve(rtx_ctx* c, const float* accum_dev, uint32_t total_spp, float* r
   return RTX_OK;
 }
 
-int rtx_trace_closest(rtx_ctx* c, const float* rays_host, size_t n, uint32_t* kind_out, uint32_t* prim_out,
+static int impl_trace_closest(rtx_ctx* c, const float* rays_host, size_t n, uint32_t* kind_out, uint32_t* prim_out,
                       float* t_out, float* normal_out) {
   if (!c || (n && (!rays_host || !kind_out || !prim_out || !t_out)))
     return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_trace_closest: null argument");
@@ -948,7 +969,7 @@ int rtx_trace_closest(rtx_ctx* c, const float* rays_host, size_t n, uint32_t* ki
   return rc;
 }
 
-int rtx_trace_occluded(rtx_ctx* c, const float* rays_host, const float* distance_host, size_t n,
+static int impl_trace_occluded(rtx_ctx* c, const float* rays_host, const float* distance_host, size_t n,
                        uint8_t* occluded_out) {
   if (!c || (n && (!rays_host || !distance_host || !occluded_out)))
     return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_trace_occluded: null argument");
@@ -983,23 +1004,54 @@ int rtx_trace_occluded(rtx_ctx* c, const float* rays_host, const float* distance
   return rc;
 }
 
-int rtx_get_stats(rtx_ctx* c, rtx_stats* out) {
+static int impl_debug_pcg(rtx_ctx* c, uint32_t seed, uint32_t n, uint32_t* rand_out, float* uniform_out,
+                          uint32_t* hash_out) {
+  if (!c) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_debug_pcg: null argument");
+  if (n == 0) return RTX_OK;
+  if (n > (1u << 20)) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_debug_pcg: at most 2^20 draws");
+  DeviceGuard g(c->device);
+  if (!g.ok) return fail(RTX_ERR_HIP, "rtx_debug_pcg: hipSetDevice failed");
+  DevBuf<uint32_t> buf;  // [rand | uniform bits | hash]
+  HIP_TRY(buf.alloc(3 * (size_t)n));
+  int rc = RTX_OK;
+  do {
+#define TRY_BREAK(expr)               \
+  {                                   \
+    hipError_t e_ = (expr);           \
+    if (e_ != hipSuccess) {           \
+      rc = fail_hip(e_, #expr);       \
+      break;                          \
+    }                                 \
+  }
+    rtx::k_debug_pcg<<<1, 64>>>(seed, n, buf.p, reinterpret_cast<float*>(buf.p + n), buf.p + 2 * (size_t)n);
+    TRY_BREAK(hipGetLastError());
+    TRY_BREAK(hipDeviceSynchronize());
+    if (rand_out) TRY_BREAK(hipMemcpy(rand_out, buf.p, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    if (uniform_out) TRY_BREAK(hipMemcpy(uniform_out, buf.p + n, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    if (hash_out) TRY_BREAK(hipMemcpy(hash_out, buf.p + 2 * (size_t)n, 4 * (size_t)n, hipMemcpyDeviceToHost));
+#undef TRY_BREAK
+  } while (0);
+  buf.release();
+  return rc;
+}
+
+static int impl_get_stats(rtx_ctx* c, rtx_stats* out) {
   if (!c || !out) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_get_stats: null argument");
   *out = c->stats;
   return RTX_OK;
 }
-int rtx_reset_stats(rtx_ctx* c) {
+static int impl_reset_stats(rtx_ctx* c) {
   if (!c) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_reset_stats: null argument");
   c->stats = rtx_stats{};
   return RTX_OK;
 }
-int rtx_set_profiling(rtx_ctx* c, int on) {
+static int impl_set_profiling(rtx_ctx* c, int on) {
   if (!c) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_set_profiling: null argument");
   c->profiling = on != 0;
   return RTX_OK;
 }
 
-int rtx_accum_alloc(rtx_ctx* c, float** out) {
+static int impl_accum_alloc(rtx_ctx* c, float** out) {
   if (!c || !out) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_accum_alloc: null argument");
   DeviceGuard g(c->device);
   if (!g.ok) return fail(RTX_ERR_HIP, "rtx_accum_alloc: hipSetDevice failed");
@@ -1008,13 +1060,13 @@ int rtx_accum_alloc(rtx_ctx* c, float** out) {
   HIP_TRY(hipMemset(*out, 0, bytes));
   return RTX_OK;
 }
-int rtx_accum_free(rtx_ctx* c, float* p) {
+static int impl_accum_free(rtx_ctx* c, float* p) {
   if (!c) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_accum_free: null argument");
   DeviceGuard g(c->device);
   if (p) HIP_TRY(hipFree(p));
   return RTX_OK;
 }
-int rtx_accum_clear(rtx_ctx* c, float* p, void* stream) {
+static int impl_accum_clear(rtx_ctx* c, float* p, void* stream) {
   if (!c || !p) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_accum_clear: null argument");
   DeviceGuard g(c->device);
   size_t bytes = (size_t)c->cfg.width * c->cfg.height * 3 * sizeof(float);
@@ -1022,7 +1074,7 @@ int rtx_accum_clear(rtx_ctx* c, float* p, void* stream) {
   return RTX_OK;
 }
 
-int rtx_accum_upload(rtx_ctx* c, float* p, const float* sums_host, void* stream) {
+static int impl_accum_upload(rtx_ctx* c, float* p, const float* sums_host, void* stream) {
   if (!c || !p || !sums_host) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_accum_upload: null argument");
   DeviceGuard g(c->device);
   if (!g.ok) return fail(RTX_ERR_HIP, "rtx_accum_upload: hipSetDevice failed");
@@ -1030,6 +1082,73 @@ int rtx_accum_upload(rtx_ctx* c, float* p, const float* sums_host, void* stream)
   HIP_TRY(hipMemcpyAsync(p, sums_host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   return RTX_OK;
+}
+
+}  // extern "C"
+
+// The exported entry points: nothing thrown inside the library (std::bad_alloc from a vector,
+// std::system_error from a worker thread) crosses the C boundary; it becomes a status code.
+namespace {
+template <typename F>
+int guarded(const char* what, F&& body) {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    return fail_nothrow(RTX_ERR_OUT_OF_MEMORY, what, "host allocation failed");
+  } catch (const std::exception& e) {
+    return fail_nothrow(RTX_ERR_HIP, what, e.what());
+  } catch (...) {
+    return fail_nothrow(RTX_ERR_HIP, what, "unknown exception");
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int rtx_create(const rtx_config* cfg, rtx_ctx** out) {
+  return guarded("rtx_create", [&] { return impl_create(cfg, out); });
+}
+int rtx_set_scene(rtx_ctx* c, const rtx_scene* s) {
+  return guarded("rtx_set_scene", [&] { return impl_set_scene(c, s); });
+}
+int rtx_get_scene_info(rtx_ctx* c, rtx_scene_info* out) {
+  return guarded("rtx_get_scene_info", [&] { return impl_get_scene_info(c, out); });
+}
+int rtx_render(rtx_ctx* c, float* accum_dev, uint32_t spp, uint32_t sample_base, uint64_t seed, const float cam_offset[3], uint32_t row0, uint32_t row1, void* stream) {
+  return guarded("rtx_render", [&] { return impl_render(c, accum_dev, spp, sample_base, seed, cam_offset, row0, row1, stream); });
+}
+int rtx_resolve(rtx_ctx* c, const float* accum_dev, uint32_t total_spp, float* rgb_out_host, void* stream) {
+  return guarded("rtx_resolve", [&] { return impl_resolve(c, accum_dev, total_spp, rgb_out_host, stream); });
+}
+int rtx_trace_closest(rtx_ctx* c, const float* rays_host, size_t n, uint32_t* kind_out, uint32_t* prim_out, float* t_out, float* normal_out) {
+  return guarded("rtx_trace_closest", [&] { return impl_trace_closest(c, rays_host, n, kind_out, prim_out, t_out, normal_out); });
+}
+int rtx_trace_occluded(rtx_ctx* c, const float* rays_host, const float* distance_host, size_t n, uint8_t* occluded_out) {
+  return guarded("rtx_trace_occluded", [&] { return impl_trace_occluded(c, rays_host, distance_host, n, occluded_out); });
+}
+int rtx_debug_pcg(rtx_ctx* c, uint32_t seed, uint32_t n, uint32_t* rand_out, float* uniform_out, uint32_t* hash_out) {
+  return guarded("rtx_debug_pcg", [&] { return impl_debug_pcg(c, seed, n, rand_out, uniform_out, hash_out); });
+}
+int rtx_get_stats(rtx_ctx* c, rtx_stats* out) {
+  return guarded("rtx_get_stats", [&] { return impl_get_stats(c, out); });
+}
+int rtx_reset_stats(rtx_ctx* c) {
+  return guarded("rtx_reset_stats", [&] { return impl_reset_stats(c); });
+}
+int rtx_set_profiling(rtx_ctx* c, int on) {
+  return guarded("rtx_set_profiling", [&] { return impl_set_profiling(c, on); });
+}
+int rtx_accum_alloc(rtx_ctx* c, float** out) {
+  return guarded("rtx_accum_alloc", [&] { return impl_accum_alloc(c, out); });
+}
+int rtx_accum_free(rtx_ctx* c, float* p) {
+  return guarded("rtx_accum_free", [&] { return impl_accum_free(c, p); });
+}
+int rtx_accum_clear(rtx_ctx* c, float* p, void* stream) {
+  return guarded("rtx_accum_clear", [&] { return impl_accum_clear(c, p, stream); });
+}
+int rtx_accum_upload(rtx_ctx* c, float* p, const float* sums_host, void* stream) {
+  return guarded("rtx_accum_upload", [&] { return impl_accum_upload(c, p, sums_host, stream); });
 }
 
 }  // extern "C"
