@@ -83,6 +83,7 @@ struct DevBuf {
     hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
     if (e != hipSuccess) {
       p = nullptr;
+      (void)hipGetLastError();  // the runtime also remembers the failure; a later hipGetLastError() check must not see it
       return e;
     }
     n = count;

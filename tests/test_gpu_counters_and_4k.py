@@ -75,7 +75,8 @@ def test_render_after_a_failed_result_buffer_allocation(rtx_lib):
     once memory is free again the same context renders the bits of a fresh one.  (The buffer
     is 12 bytes per sample of a chunk, at most 2^32 samples = 51.5 GB; the test first fills
     the device with ballast so that this does not fit.)"""
-    import torch
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so.7")  # the runtime the library is linked against (already loaded)
     sc = scenes.cornell()
     W, H, spp = 256, 256, 8
     with Renderer(Config(width=W, height=H, pool_paths=1 << 14)) as r:
@@ -86,15 +87,16 @@ def test_render_after_a_failed_result_buffer_allocation(rtx_lib):
     with Renderer(Config(width=W, height=H, pool_paths=1 << 14, result_buffer_mib=64 * 1024)) as r:
         r.set_scene(sc)
         acc = r.accum_alloc()
-        free, _ = torch.cuda.mem_get_info()
-        ballast = torch.empty(max(free - (16 << 30), 0), dtype=torch.uint8, device="cuda")
+        free, total = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        ballast = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(ballast), ctypes.c_size_t(max(free.value - (16 << 30), 1 << 20))) == 0
         try:
             with pytest.raises(RtxError) as e:
                 r.render(acc, 70000)  # one chunk of 65535 spp * 256*256 * 12 B = 51.5 GB
             assert e.value.status == -4, e.value  # RTX_ERR_OUT_OF_MEMORY
         finally:
-            del ballast
-            torch.cuda.empty_cache()
+            assert hip.hipFree(ballast) == 0
         r.accum_clear(acc)
         # The failed call must not have left a "large enough" null buffer behind.
         r.render(acc, spp)
