@@ -209,6 +209,16 @@ int rtx_resolve(rtx_ctx* ctx, const float* accum_dev, uint32_t total_spp, float*
  * (+inf on a miss).  Synchronous. */
 int rtx_trace_closest(rtx_ctx* ctx, const float* rays_host, size_t n, uint32_t* kind_out,
                       uint32_t* prim_out, float* t_out, float* normal_out);
+/* rtx_trace_closest for callers that must not allocate device memory (tight serving loops,
+ * harnesses that forbid hipMalloc, code that cannot tolerate an allocation's implicit
+ * synchronisation).  It has no counterpart in the reference.  Same arguments, same results
+ * bit for bit, but no hipMalloc/hipFree on the call path: rays and results are staged in a
+ * 12.6 MB array that is part of the library's device image on every GPU it runs on (held
+ * until the process ends).  n is at most 262144 rays per call; a larger n fails with
+ * RTX_ERR_INVALID_ARGUMENT.  All contexts on one GPU share that GPU's array: calls that
+ * overlap in time on one GPU (from two threads or two contexts) race.  Synchronous. */
+int rtx_trace_closest_noalloc(rtx_ctx* ctx, const float* rays_host, size_t n, uint32_t* kind_out,
+                              uint32_t* prim_out, float* t_out, float* normal_out);
 /* Scene::isOccluded (Scene.h:191-225) for n segments: occluded_out[i] in {0,1}. */
 int rtx_trace_occluded(rtx_ctx* ctx, const float* rays_host, const float* distance_host, size_t n,
                        uint8_t* occluded_out);

@@ -95,7 +95,7 @@ SYMBOLS = [
     "rtx_last_error", "rtx_create", "rtx_destroy", "rtx_set_scene", "rtx_get_scene_info",
     "rtx_render", "rtx_resolve", "rtx_trace_closest", "rtx_trace_occluded", "rtx_get_stats",
     "rtx_reset_stats", "rtx_set_profiling", "rtx_accum_alloc", "rtx_accum_free", "rtx_accum_clear",
-    "rtx_accum_upload", "rtx_debug_pcg",
+    "rtx_accum_upload", "rtx_debug_pcg", "rtx_trace_closest_noalloc",
 ]
 
 _lib = None
@@ -124,6 +124,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rtx_render.argtypes = [vp, vp, u32, u32, u64, fp, u32, u32, vp]
     lib.rtx_resolve.argtypes = [vp, vp, u32, vp, vp]
     lib.rtx_trace_closest.argtypes = [vp, vp, sz, vp, vp, vp, vp]
+    lib.rtx_trace_closest_noalloc.argtypes = [vp, vp, sz, vp, vp, vp, vp]
     lib.rtx_trace_occluded.argtypes = [vp, vp, vp, sz, vp]
     lib.rtx_get_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.rtx_reset_stats.argtypes = [vp]
@@ -307,15 +308,16 @@ class Renderer:
         return out
 
     # -- fixed ray sets ------------------------------------------------------------
-    def trace_closest(self, rays: np.ndarray, want_normal: bool = True):
+    def trace_closest(self, rays: np.ndarray, want_normal: bool = True, noalloc: bool = False):
+        """noalloc: through rtx_trace_closest_noalloc (no device allocation on the call path)."""
         rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
         n = rays.shape[0]
         kind = np.empty(n, np.uint32)
         prim = np.empty(n, np.uint32)
         t = np.empty(n, np.float32)
         nrm = np.empty((n, 3), np.float32) if want_normal else None
-        self._check(self.lib.rtx_trace_closest(self._ctx, _ptr(rays), n, _ptr(kind), _ptr(prim),
-                                               _ptr(t), _ptr(nrm)))
+        fn = self.lib.rtx_trace_closest_noalloc if noalloc else self.lib.rtx_trace_closest
+        self._check(fn(self._ctx, _ptr(rays), n, _ptr(kind), _ptr(prim), _ptr(t), _ptr(nrm)))
         return kind, prim, t, nrm
 
     def trace_occluded(self, rays: np.ndarray, dist: np.ndarray) -> np.ndarray:

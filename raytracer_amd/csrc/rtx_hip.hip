@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -70,6 +71,30 @@ constexpr bool kTightEnd = RTX_TIGHT_END != 0;
 constexpr size_t kFusedSmallSceneBytes = 4096;  // k_trace_shade: scenes up to this size run 128-thread blocks
 constexpr uint32_t kTraceBatches = 2;  // ray batches per block of k_intersect/k_shadow (the next batch's loads overlap the current traversal)
 constexpr int kPollSlots = 4;
+
+// rtx_trace_closest_noalloc: staging for the rays and the results of one call, in device memory
+// the library owns from load time on (no hipMalloc on the call path).  One copy per GPU; every
+// call on a GPU shares it.  Layout in 32-bit words, N = kNoAllocMaxRays:
+//   [0, 6N) rays | [6N, 7N) t | [7N, 8N) kind | [8N, 9N) primitive | [9N, 12N) normal
+constexpr size_t kNoAllocMaxRays = 1u << 18;
+constexpr size_t kScratchWords = 12 * kNoAllocMaxRays;  // 12.6 MB per GPU
+constexpr int kMaxDevices = 64;
+static __device__ __align__(256) uint32_t scratch[kScratchWords];
+// The array's address on each device, looked up once per device with that device current
+// (in host code the name `scratch` is only a handle for hipGetSymbolAddress, not an address).
+uint32_t* g_scratch_ptr[kMaxDevices] = {};
+std::mutex g_scratch_mutex;
+
+int resolve_scratch(int dev) {  // the device `dev` is current
+  if (dev < 0 || dev >= kMaxDevices) return fail(RTX_ERR_UNSUPPORTED, "device ordinal above 63");
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (g_scratch_ptr[dev]) return RTX_OK;
+  void* ptr = nullptr;
+  hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+  if (e != hipSuccess || !ptr) return fail_hip(e, "hipGetSymbolAddress(scratch)");
+  g_scratch_ptr[dev] = static_cast<uint32_t*>(ptr);
+  return RTX_OK;
+}
 
 template <typename T>
 struct DevBuf {
@@ -248,6 +273,10 @@ static int impl_create(const rtx_config* cfg, rtx_ctx** out) {
   if (!g.ok) {
     delete c;
     return fail(RTX_ERR_HIP, "rtx_create: hipSetDevice failed");
+  }
+  if (int rc = resolve_scratch(dev)) {
+    delete c;
+    return rc;
   }
   // Loop-invariant camera terms (Camera.h:19-20): the tanf argument is evaluated in
   // double (M_PI) and narrowed, as in the reference.
@@ -970,6 +999,49 @@ static int impl_trace_closest(rtx_ctx* c, const float* rays_host, size_t n, uint
   return rc;
 }
 
+// rtx_trace_closest without an allocation on the call path: the rays and the results are staged
+// in this GPU's `scratch` array (through the pointer looked up at rtx_create, never through the
+// array's name), the traversal stacks use the spill columns rtx_set_scene allocated.
+static int impl_trace_closest_noalloc(rtx_ctx* c, const float* rays_host, size_t n, uint32_t* kind_out,
+                                      uint32_t* prim_out, float* t_out, float* normal_out) {
+  if (!c || (n && (!rays_host || !kind_out || !prim_out || !t_out)))
+    return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_trace_closest_noalloc: null argument");
+  if (!c->have_scene) return fail(RTX_ERR_NO_SCENE, "rtx_trace_closest_noalloc: no scene set");
+  if (n == 0) return RTX_OK;
+  if (n > kNoAllocMaxRays)
+    return fail(RTX_ERR_INVALID_ARGUMENT,
+                "rtx_trace_closest_noalloc: more than 262144 rays in one call (use rtx_trace_closest, or split the call)");
+  DeviceGuard g(c->device);
+  if (!g.ok) return fail(RTX_ERR_HIP, "rtx_trace_closest_noalloc: hipSetDevice failed");
+  uint32_t* const base = g_scratch_ptr[c->device];
+  if (!base) return fail(RTX_ERR_HIP, "rtx_trace_closest_noalloc: scratch address not resolved for this device");
+  constexpr size_t N = kNoAllocMaxRays;
+  float* rays = reinterpret_cast<float*>(base);
+  float* t = reinterpret_cast<float*>(base + 6 * N);
+  uint32_t* kind = base + 7 * N;
+  uint32_t* prim = base + 8 * N;
+  float* nrm = reinterpret_cast<float*>(base + 9 * N);
+  // Every word a call reads back is written by its own kernel first (one thread per ray writes
+  // t, kind, primitive and normal), so nothing of the previous call's contents has to be cleared.
+  HIP_TRY(hipMemcpy(rays, rays_host, n * 6 * sizeof(float), hipMemcpyHostToDevice));
+  const size_t lds = (size_t)c->stack_entries * kTraceBlock * sizeof(int) +
+                     (c->trace_mode == rtx::kLdsBvh2 ? c->lds_scene_bytes : 0);
+  const rtx::TraceParams tp{c->stack_entries, c->spill.p, c->pool};
+  for (size_t first = 0; first < n; first += c->pool) {  // at most pool rays per launch (spill columns)
+    const uint32_t m = (uint32_t)std::min<size_t>(c->pool, n - first);
+    RTX_BY_MODE(c->trace_mode, rtx::k_trace_closest, kTraceBlock, (div_up(m, kTraceBlock), kTraceBlock, lds, 0),
+                (c->scene, rays + 6 * first, m, kind + first, prim + first, t + first,
+                 normal_out ? nrm + 3 * first : nullptr, tp));
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(kind_out, kind, n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(prim_out, prim, n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(t_out, t, n * 4, hipMemcpyDeviceToHost));
+  if (normal_out) HIP_TRY(hipMemcpy(normal_out, nrm, n * 12, hipMemcpyDeviceToHost));
+  return RTX_OK;
+}
+
 static int impl_trace_occluded(rtx_ctx* c, const float* rays_host, const float* distance_host, size_t n,
                        uint8_t* occluded_out) {
   if (!c || (n && (!rays_host || !distance_host || !occluded_out)))
@@ -1123,6 +1195,9 @@ int rtx_resolve(rtx_ctx* c, const float* accum_dev, uint32_t total_spp, float* r
 }
 int rtx_trace_closest(rtx_ctx* c, const float* rays_host, size_t n, uint32_t* kind_out, uint32_t* prim_out, float* t_out, float* normal_out) {
   return guarded("rtx_trace_closest", [&] { return impl_trace_closest(c, rays_host, n, kind_out, prim_out, t_out, normal_out); });
+}
+int rtx_trace_closest_noalloc(rtx_ctx* c, const float* rays_host, size_t n, uint32_t* kind_out, uint32_t* prim_out, float* t_out, float* normal_out) {
+  return guarded("rtx_trace_closest_noalloc", [&] { return impl_trace_closest_noalloc(c, rays_host, n, kind_out, prim_out, t_out, normal_out); });
 }
 int rtx_trace_occluded(rtx_ctx* c, const float* rays_host, const float* distance_host, size_t n, uint8_t* occluded_out) {
   return guarded("rtx_trace_occluded", [&] { return impl_trace_occluded(c, rays_host, distance_host, n, occluded_out); });
