@@ -9,18 +9,32 @@ buffer that is already resident (no host transfers in the timed region).  The
 default workload is BASELINE.json's configs[1], the one its metric is quoted on:
 the glass-sphere scene ("sample2") at 1024x1024, 256 samples per pixel.
 
-N > 1 (launched by torch.distributed.run, one process per GPU): every rank renders
-the whole frame with its own, disjoint range of 256 sample indices (weak scaling:
-the per-GPU work is the N=1 workload) and the per-GPU sum buffers are added onto
-rank 0 with one RCCL reduce over xGMI, inside the timed region.
+N > 1: one process per GPU.  Launched by torch.distributed.run the ranks are already
+there; typed as a plain command, this process starts them itself (before it touches
+the GPU) and passes rank 0's line through.  Every rank renders the whole frame with
+its own, disjoint range of 256 sample indices (weak scaling: the per-GPU work is the
+N=1 workload) and the per-GPU sum buffers are added onto rank 0 with one RCCL reduce
+over xGMI, inside the timed region.
 
 One JSON line is printed by rank 0.  Besides the contract's fields it carries
-  roofline      the dominant kernel's algorithmic bytes per launch / its average
-                launch duration (HIP events on the render stream), against HBM peak;
-  cpu_baseline  the CPU oracle (a port of the reference's OpenMP loop) timed on
-                this host on a bounded sample of the same workload.
+  roofline      for the dominant kernel (by HIP-event time on the render stream):
+                `traffic` = HBM bytes per launch from the committed counter passes,
+                `achieved` = traffic / the launch duration measured live here, `frac` =
+                achieved / 8 TB/s; beside it the VALU issue fraction and the lanes
+                active per VALU instruction from the committed SQ counter passes, and
+                the algorithmic-bytes figure (minimum queue traffic of a wavefront
+                design: 164 B per bounce, 88 B per shadow ray, 52 B per primary
+                sample) with a note where that model exceeds what the kernel moves.
+                `bound` is "hbm" or "valu", whichever fraction is larger, or
+                "latency" when both are under one half;
+  cpu_baseline  the CPU oracle (a port of the reference's OpenMP loop) timed on this
+                host on a bounded sample of the same workload, at all of the host's
+                cores and at the reference's own 8 threads (Raytracer.cpp:41);
+  mis_cornell   a second, short leg on the MIS Cornell scene (1024x1024, 256 spp)
+                with its own CPU baseline.
 """
 import argparse
+import csv
 import json
 import os
 import sys
@@ -31,16 +45,23 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+SIMDS = 256 * 4        # MI355X: 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9       # peak engine clock used to turn a launch duration into issue slots
+VALU_CYCLES = 2        # issue cycles of one wave64 VALU instruction at full rate
 
-# Algorithmic bytes per unit: the minimum queue traffic of a wavefront design.
-# Path state = o,d (24) + attenuation (12) + pixel (4) + rng (4) + mis_brdf_pdf (4) + nee_pdf (4) = 52 B.
+# Algorithmic bytes per unit: the minimum queue traffic of a wavefront design with one kernel
+# per stage.  Path state = o,d (24) + attenuation (12) + pixel (4) + rng (4) + mis_brdf_pdf (4)
+# + nee_pdf (4) = 52 B.  Per bounce: 52 read + 52 written by shade, 24 ray re-read by intersect,
+# 8 + 8 hit record, 4 + 4 compaction index, 12 radiance = 164 B.
 BYTES = {
-    "intersect": 24 + 8,                  # ray read + hit record written
-    "shade": 52 + 8 + 52 + 4 + 4 + 12,    # state read, hit read, state written, compaction index r/w, radiance RMW
-    "trace_shade": 52 + 52 + 4 + 4 + 12,  # search and shading in one kernel: no ray or hit record in between
-    "shadow": 44 + 44,                    # shadow record written by shade and read by shadow
-    "generate": 52,                       # state written per primary sample
+    "intersect": 24 + 8,
+    "shade": 52 + 8 + 52 + 4 + 4 + 12,
+    "trace_shade": 164,   # one kernel does the whole bounce: it is charged the whole bounce
+    "shadow": 44 + 44,
+    "generate": 52,
 }
+KERNEL_PREFIX = {"intersect": "k_intersect", "shade": "k_shade", "trace_shade": "k_trace_shade",
+                 "shadow": "k_shadow", "generate": "k_generate"}
 
 
 def workloads():
@@ -53,100 +74,180 @@ def workloads():
         "mesh_1m": dict(scene=lambda: scenes.terrain(707), sky=0, width=1920, height=1080, spp=256),
         "soup150": dict(scene=lambda: scenes.soup(150, 3, seed=2), sky=1, width=1024, height=1024, spp=64),
         "soup3k": dict(scene=lambda: scenes.soup(3000, 3, seed=2), sky=1, width=1024, height=1024, spp=64),
+        "terrain40": dict(scene=lambda: scenes.terrain(40), sky=0, width=1024, height=1024, spp=64),
         "mis_4k": dict(scene=lambda: scenes.cornell(), sky=0, width=3840, height=2160, spp=4096),
     }
 
 
-def pmc_traffic(workload, kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE over this same command, reduced by tools/pmc_traffic.py).
-    Counters cannot be read from inside this process, so the figure comes from the file."""
-    path = os.path.join(ROOT, "profiles", f"pmc_traffic_{workload}.json")
+# ---- committed profiler evidence (counters cannot be read from inside this process) ------------
+def _load_json(path):
     try:
-        kernels = json.load(open(path))["kernels"]
-        name = next(k for k in sorted(kernels) if k.startswith(kernel))  # k_shade -> k_shade_wave_append, ...
-        return round(kernels[name]["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT)
-    except (OSError, KeyError, ValueError, StopIteration):
+        return json.load(open(path))
+    except (OSError, ValueError):
+        return None
+
+
+def _kernel_entry(table, prefix):
+    """The entry of the first kernel (by name) that starts with `prefix` (k_shade -> k_shade_block_append)."""
+    if not table:
         return None, None
+    for name in sorted(table):
+        if name.startswith(prefix):
+            return name, table[name]
+    return None, None
 
 
-def cpu_baseline(sc, cfg, spp_full, budget_s=12.0):
-    """Times the oracle (OpenMP rows, dynamic schedule) on a bounded sample: the same
-    frame at as many samples per pixel as fit the time budget."""
+def pmc_traffic(workload, prefix):
+    """HBM bytes per launch from the --pmc FETCH_SIZE / WRITE_SIZE passes over this same command
+    (tools/profile_round.sh, reduced by tools/pmc_traffic.py with the gfx950 corrections)."""
+    path = os.path.join(ROOT, "profiles", f"pmc_traffic_{workload}.json")
+    d = _load_json(path)
+    _, e = _kernel_entry(d and d.get("kernels"), prefix)
+    if not e:
+        return None, None
+    return round(e["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT)
+
+
+def sq_counters(workload, prefix):
+    """Per-launch means of the SQ counters of one kernel (tools/profile_round.sh, tools/pmc_sq.py)."""
+    path = os.path.join(ROOT, "profiles", f"sq_counters_{workload}.json")
+    d = _load_json(path)
+    _, e = _kernel_entry(d and d.get("kernels"), prefix)
+    return (e, os.path.relpath(path, ROOT)) if e else (None, None)
+
+
+def rocprof_average_ms(workload, prefix):
+    """Average launch duration of the kernel in the committed rocprofv3 --kernel-trace --stats summary."""
+    path = os.path.join(ROOT, "profiles", f"kernel_stats_{workload}.csv")
+    try:
+        for row in csv.DictReader(open(path)):
+            name = row["Name"].split("(")[0].split("::")[-1].split("<")[0]
+            if name.startswith(prefix):
+                return float(row["AverageNs"]) * 1e-6, os.path.relpath(path, ROOT)
+    except (OSError, KeyError, ValueError):
+        pass
+    return None, None
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def host_threads():
+    """The cores this process may use: the box's share where the launcher exported one
+    (OMP_NUM_THREADS), else what the scheduler allows, else the machine's count."""
+    env = os.environ.get("OMP_NUM_THREADS", "")
+    if env.isdigit() and int(env) > 0:
+        return int(env)
+    try:
+        return len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(sc, cfg, spp_full, budget_s=9.0):
+    """Times the oracle (OpenMP rows, dynamic schedule: the shape of Raytracer.cpp:242) on a
+    bounded sample of the workload: the same frame at as many samples per pixel as fit the
+    budget, once with every core this process may use and once with the reference's THREADS = 8."""
     from oracle import oracle_py
-    threads = min(16, os.cpu_count() or 1)
     osc = oracle_py.OracleScene(sc, cfg)
     rows = max(8, cfg.height // 16)
-    t0 = time.perf_counter()
-    _, st = osc.render(1, nthreads=threads, row0=0, row1=rows)  # calibration: a band of rows
-    dt = max(time.perf_counter() - t0, 1e-4)
-    per_spp_s = dt * cfg.height / rows
-    spp = int(max(1, min(spp_full, budget_s / per_spp_s)))
-    t0 = time.perf_counter()
-    _, st = osc.render(spp, nthreads=threads)
-    dt = time.perf_counter() - t0
+
+    def timed(threads):
+        t0 = time.perf_counter()
+        osc.render(1, nthreads=threads, row0=0, row1=rows)  # calibration: a band of rows
+        dt = max(time.perf_counter() - t0, 1e-4)
+        per_spp_s = dt * cfg.height / rows
+        spp = int(max(1, min(spp_full, budget_s / per_spp_s)))
+        t0 = time.perf_counter()
+        _, st = osc.render(spp, nthreads=threads)
+        dt = time.perf_counter() - t0
+        return {"value": round(st.bounces / dt / 1e6, 3), "cores": threads,
+                "sample": f"{cfg.width}x{cfg.height}, {spp} of {spp_full} spp, {st.paths} paths in {dt:.2f} s "
+                          f"({st.paths / dt / 1e6:.3f} Mpaths/s)"}
+
+    allc = timed(host_threads())
+    eight = timed(min(8, host_threads()))
     return {
-        "value": round(st.bounces / dt / 1e6, 3), "unit": "Mpath-bounces/s", "cores": threads,
-        "kind": "port",
-        "sample": f"{cfg.width}x{cfg.height}, {spp} of {spp_full} spp, {st.paths} paths in {dt:.2f} s "
-                  f"(oracle BVH in place of Embree; {st.paths / dt / 1e6:.3f} Mpaths/s)",
+        "value": allc["value"], "unit": "Mpath-bounces/s", "cores": allc["cores"], "kind": "port",
+        "sample": allc["sample"] + "; reference algorithm on the oracle's own BVH, not Embree",
+        "cpu_model": cpu_model(),
+        "threads8": {"value": eight["value"], "cores": eight["cores"], "sample": eight["sample"],
+                     "note": "THREADS = 8 as in Raytracer.cpp:41"},
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="sample2_glass")
-    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel")
-    ap.add_argument("--width", type=int, default=0)
-    ap.add_argument("--height", type=int, default=0)
-    ap.add_argument("--pool", type=int, default=0, help="in-flight path pool (0 = library default)")
-    ap.add_argument("--finish-paths", type=int, default=0, help="drain-kernel threshold (0 = library default)")
-    ap.add_argument("--fused-trace", type=int, default=0, choices=[0, 1, 2],
-                    help="rtx_config.fused_trace: 0 library chooses, 1 search and shading in two kernels, 2 in one")
-    ap.add_argument("--primary-rays", type=int, default=0, choices=[0, 1],
-                    help="1 = primary rays always written by the generate kernel and read back (0 = library's choice)")
-    ap.add_argument("--strong", action="store_true", help="split the workload's spp across ranks instead")
-    ap.add_argument("--tiles", type=int, default=1,
-                    help="row bands: ranks form TILES groups, group g renders band g of the frame and the "
-                         "ranks of a group take disjoint sample ranges (for frames too large per GPU)")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo + RTX_BENCH_SAME_GPU=1 rehearses the N>1 logic on one GPU (buffers are summed "
-                         "through host memory); the real run uses nccl = RCCL")
-    args = ap.parse_args()
+def build_roofline(workload, stage, fused):
+    """The roofline object for the stage with the largest HIP-event time."""
+    dom = max(stage, key=lambda k: stage[k][0])
+    ms, launches, units = stage[dom]
+    if dom == "shade" and fused:
+        dom = "trace_shade"
+    if not launches or ms <= 0:
+        return None
+    prefix = KERNEL_PREFIX[dom]
+    avg_ms = ms / launches
+    alg_launch = BYTES[dom] * units / launches
+    alg_gbs = alg_launch / (avg_ms * 1e-3) / 1e9
+    traffic, traffic_src = pmc_traffic(workload, prefix)
+    sq, sq_src = sq_counters(workload, prefix)
+    prof_ms, prof_src = rocprof_average_ms(workload, prefix)
+    hbm_gbs = traffic / (avg_ms * 1e-3) / 1e9 if traffic else None
+    hbm_frac = hbm_gbs / HBM_PEAK_GBS if hbm_gbs else None
+    valu_frac = lanes = None
+    if sq and sq.get("SQ_INSTS_VALU"):
+        # issue slots the launch's VALU instructions need / issue slots the chip has in its duration
+        valu_frac = sq["SQ_INSTS_VALU"] * VALU_CYCLES / (avg_ms * 1e-3 * CLOCK_HZ * SIMDS)
+        if sq.get("SQ_THREAD_CYCLES_VALU") and sq.get("SQ_ACTIVE_INST_VALU"):
+            lanes = sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_ACTIVE_INST_VALU"]
+    fr = [f for f in (hbm_frac, valu_frac) if f is not None]
+    if not fr:
+        bound = "hbm"
+    elif max(fr) < 0.5:
+        bound = "latency"
+    else:
+        bound = "hbm" if (hbm_frac or 0) >= (valu_frac or 0) else "valu"
+    roof = {
+        "bound": bound, "kernel": prefix,
+        "achieved": round(hbm_gbs, 2) if hbm_gbs else round(alg_gbs, 2),
+        "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round((hbm_gbs if hbm_gbs else alg_gbs) / HBM_PEAK_GBS, 5),
+        "achieved_is": "counter HBM bytes per launch / live launch duration" if hbm_gbs else
+                       "algorithmic bytes per launch / live launch duration (no counter file for this workload)",
+        "traffic": traffic, "traffic_source": traffic_src,
+        "avg_launch_ms": round(avg_ms, 5), "launches": int(launches),
+        "units_per_launch": round(units / launches, 1),
+        "rocprof_avg_launch_ms": round(prof_ms, 5) if prof_ms else None, "rocprof_source": prof_src,
+        "valu_issue_frac": round(valu_frac, 4) if valu_frac is not None else None,
+        "valu_issue_formula": "SQ_INSTS_VALU per launch x 2 cycles / (avg_launch_s x 2.4 GHz x 1024 SIMDs)",
+        "lanes_active": round(lanes, 2) if lanes is not None else None,
+        "sq_source": sq_src,
+        "algorithmic": {
+            "bytes_per_unit": BYTES[dom], "bytes_per_launch": round(alg_launch),
+            "gbs": round(alg_gbs, 2), "frac_of_peak": round(alg_gbs / HBM_PEAK_GBS, 5),
+        },
+    }
+    if traffic and alg_launch > traffic:
+        roof["algorithmic"]["note"] = (
+            "the byte model counts queue traffic this kernel does not move (search and shading in one "
+            "kernel: no ray re-read or hit record; primary rays recomputed; fresh and finished paths "
+            "skip half their state)" + ("; it exceeds the HBM peak" if alg_gbs > HBM_PEAK_GBS else ""))
+    return roof
 
-    import torch
-    import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the renderer has no CPU path")
-    if os.environ.get("RTX_BENCH_SAME_GPU") == "1":
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")
-
+def run_leg(args, workload, world, rank, local_rank, steps, warmup, profile, torch, dist):
+    """Renders `workload` warmup + steps times; returns the measurements of this rank's view."""
     from raytracer_amd.capi import Config, Renderer
-
-    wl = workloads()[args.workload]
+    wl = workloads()[workload]
     W = args.width or wl["width"]
     H = args.height or wl["height"]
     spp_full = args.spp or wl["spp"]
-    if world % args.tiles:
-        raise SystemExit("--tiles must divide the number of ranks")
     band, replica, replicas = rank % args.tiles, rank // args.tiles, world // args.tiles
     row0, row1 = band * H // args.tiles, (band + 1) * H // args.tiles
     if args.strong:
@@ -157,13 +258,11 @@ def main():
     cfg = Config(width=W, height=H, sky=wl["sky"], device=local_rank, pool_paths=args.pool,
                  finish_paths=args.finish_paths, primary_rays=args.primary_rays, fused_trace=args.fused_trace)
     sc = wl["scene"]()
-
     r = Renderer(cfg)
     info = r.set_scene(sc)
     # Two sum buffers, used in turn: the RCCL reduce of one step runs on RCCL's stream while the
     # next step renders into the other buffer.
     accums = [torch.zeros(H * W * 3, dtype=torch.float32, device="cuda") for _ in range(2 if world > 1 else 1)]
-    accum = accums[0]
     pending = [None] * len(accums)
     stream = torch.cuda.current_stream().cuda_stream
     step_no = [0]
@@ -199,38 +298,36 @@ def main():
         # Communicator set-up (RCCL builds its rings on the first collective) stays outside
         # the timed region whatever --warmup is.
         if args.backend == "nccl":
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+            dist.reduce(accums[0], dst=0, op=dist.ReduceOp.SUM)
         dist.barrier()
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     fence()
     r.reset_stats()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
     st = r.stats()
 
     tvals = torch.tensor([elapsed, float(st.bounces), float(st.paths), float(st.shadow_rays),
-                          float(st.nee_samples)], dtype=torch.float64,
-                         device="cuda" if args.backend == "nccl" else "cpu")
+                          float(st.nee_samples), float(st.nan_paths), float(st.truncated_paths)],
+                         dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
         tmax = tvals.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tvals, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0])
-    bounces, paths, shadows, nee = (float(tvals[i]) for i in range(1, 5))
+    bounces, paths, shadows, nee, nans, truncated = (float(tvals[i]) for i in range(1, 7))
 
     # Per-kernel pass: the same step once more with HIP events around every launch.
-    roof = None
-    stage = {}
-    extra_ms = {}
-    if rank == 0 and not args.no_profile:
+    stage, extra_ms, roof = {}, {}, None
+    if rank == 0 and profile:
         r.reset_stats()
         r.set_profiling(True)
-        accum.zero_()
-        r.render(accum, spp, sample_base=base, seed=0x5EED, row0=row0, row1=row1, stream=stream)
+        accums[0].zero_()
+        r.render(accums[0], spp, sample_base=base, seed=0x5EED, row0=row0, row1=row1, stream=stream)
         torch.cuda.synchronize()
         r.set_profiling(False)
         p = r.stats()
@@ -241,27 +338,85 @@ def main():
             "generate": (p.ms_generate, p.timed_launches_generate, p.paths),
         }
         extra_ms = {"finish": p.ms_finish, "reduce": p.ms_reduce}
-        dom = max(stage, key=lambda k: stage[k][0])
-        ms, launches, units = stage[dom]
-        fused = p.timed_launches_intersect == 0      # k_trace_shade is timed as the shade stage
-        if dom == "shade" and fused:
-            dom = "trace_shade"
-        if launches and ms > 0:
-            bytes_per_launch = BYTES[dom] * units / launches
-            avg_ms = ms / launches
-            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-            traffic, traffic_src = pmc_traffic(args.workload, "k_" + dom)
-            roof = {"bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "traffic_source": traffic_src, "algorithmic_bytes_per_launch": round(bytes_per_launch),
-                    "algorithmic_bytes_per_unit": BYTES[dom], "units_per_launch": round(units / launches, 1),
-                    "avg_launch_ms": round(avg_ms, 5), "launches": int(launches)}
+        roof = build_roofline(workload, stage, fused=p.timed_launches_intersect == 0)
     if world > 1:
         dist.barrier()
+    r.close()
+    del accums
+    return dict(W=W, H=H, spp_full=spp_full, cfg=cfg, scene=sc, info=info, elapsed=elapsed, steps=steps,
+                bounces=bounces, paths=paths, shadows=shadows, nee=nee, nans=nans, truncated=truncated,
+                stage=stage, extra_ms=extra_ms, roofline=roof)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="sample2_glass")
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--pool", type=int, default=0, help="in-flight path pool (0 = library default)")
+    ap.add_argument("--finish-paths", type=int, default=0, help="drain-kernel threshold (0 = library default)")
+    ap.add_argument("--fused-trace", type=int, default=0, choices=[0, 1, 2],
+                    help="rtx_config.fused_trace: 0 library chooses, 1 search and shading in two kernels, 2 in one")
+    ap.add_argument("--primary-rays", type=int, default=0, choices=[0, 1],
+                    help="1 = primary rays always written by the generate kernel and read back (0 = library's choice)")
+    ap.add_argument("--strong", action="store_true", help="split the workload's spp across ranks instead")
+    ap.add_argument("--tiles", type=int, default=1,
+                    help="row bands: ranks form TILES groups, group g renders band g of the frame and the "
+                         "ranks of a group take disjoint sample ranges (for frames too large per GPU)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
+    ap.add_argument("--no-mis", action="store_true", help="skip the second leg on the MIS Cornell scene")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + RTX_BENCH_SAME_GPU=1 rehearses the N>1 logic on one GPU (buffers are summed "
+                         "through host memory); the real run uses nccl = RCCL")
+    args = ap.parse_args()
+
+    # Typed as a plain command with N > 1: start one child process per GPU now, before this
+    # process has made any GPU call, and hand rank 0's line through.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        from raytracer_amd.dist import spawn_local_ranks
+        sys.exit(spawn_local_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the renderer has no CPU path")
+    if os.environ.get("RTX_BENCH_SAME_GPU") == "1":
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    if world % args.tiles:
+        raise SystemExit("--tiles must divide the number of ranks")
+    if world > 1:
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+
+    m = run_leg(args, args.workload, world, rank, local_rank, args.steps, args.warmup,
+                profile=not args.no_profile, torch=torch, dist=dist)
+
+    # Second leg (one GPU, default workload only): the closed Cornell box with next-event
+    # estimation and MIS, the scene the >= 100x-over-CPU target is stated on.
+    mis = None
+    if world == 1 and not args.no_mis and args.workload == "sample2_glass" and not (args.spp or args.width or args.height):
+        mis = run_leg(args, "sample3_mis_cornell", 1, 0, local_rank, steps=2, warmup=1,
+                      profile=not args.no_profile, torch=torch, dist=dist)
 
     if rank == 0:
-        fused_run = bool(stage) and stage["intersect"][1] == 0
-        pipeline_bytes = (124 if fused_run else 164) * bounces + 88 * shadows + 52 * paths
+        W, H, spp_full, info = m["W"], m["H"], m["spp_full"], m["info"]
+        elapsed, bounces, paths, shadows = m["elapsed"], m["bounces"], m["paths"], m["shadows"]
+        stage = m["stage"]
+        pipeline_bytes = 164 * bounces + 88 * shadows + 52 * paths
         out = {
             "metric": "Mpath-bounces/sec & time-to-image (1024², 256 spp) at 1/2/4/8 GPUs",
             "value": round(bounces / elapsed / 1e6, 2),
@@ -274,29 +429,51 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload} {W}x{H} {spp_full} spp" +
-                                   (" per GPU (disjoint sample ranges, RCCL reduce)" if world > 1 and not args.strong else "") +
+                                   (f" per GPU (disjoint sample ranges, {'RCCL' if args.backend == 'nccl' else 'gloo'} reduce)" if world > 1 and not args.strong else "") +
                                    (f", {args.tiles} row bands" if args.tiles > 1 else ""),
                        "triangles": int(info.num_triangles), "spheres": int(info.num_spheres),
                        "lights": int(info.num_lights), "bvh_nodes": int(info.num_nodes),
-                       "pool_paths": int(args.pool) or (1 << 24)},
+                       "bvh_width": int(info.bvh_width), "pool_paths": int(args.pool) or (1 << 24)},
             "time_to_image_ms": round(elapsed / args.steps * 1e3, 3),
             "mpaths_per_s": round(paths / elapsed / 1e6, 2),
+            "mshadow_rays_per_s": round(shadows / elapsed / 1e6, 2),
             "bounces_per_path": round(bounces / max(paths, 1), 3),
             "shadow_rays_per_path": round(shadows / max(paths, 1), 3),
+            "nan_paths": int(m["nans"]), "truncated_paths": int(m["truncated"]),
             "pipeline_algorithmic_gbs": round(pipeline_bytes / elapsed / 1e9, 2),
-            "pipeline_frac_of_hbm_peak": round(pipeline_bytes / elapsed / 1e9 / HBM_PEAK_GBS, 5),
+            "pipeline_algorithmic_frac_of_hbm_peak": round(pipeline_bytes / elapsed / 1e9 / HBM_PEAK_GBS, 5),
             "stage_ms": {**{k: round(v[0], 3) for k, v in stage.items()},
-                         **{k: round(v, 3) for k, v in (extra_ms if stage else {}).items()}},
-            "roofline": roof,
+                         **{k: round(v, 3) for k, v in (m["extra_ms"] if stage else {}).items()}},
+            "roofline": m["roofline"],
         }
         if not args.no_cpu and world == 1:
-            cpu = cpu_baseline(sc, cfg, spp_full)
+            cpu = cpu_baseline(m["scene"], m["cfg"], spp_full)
             out["cpu_baseline"] = cpu
             out["gpu_over_cpu"] = round(out["value"] / cpu["value"], 1) if cpu["value"] else None
+            out["gpu_over_cpu_8_threads"] = (round(out["value"] / cpu["threads8"]["value"], 1)
+                                             if cpu["threads8"]["value"] else None)
         else:
             out["cpu_baseline"] = None
+        if mis is not None:
+            mv = mis["bounces"] / mis["elapsed"] / 1e6
+            leg = {
+                "workload": f"sample3_mis_cornell {mis['W']}x{mis['H']} {mis['spp_full']} spp",
+                "steps": mis["steps"], "ms_per_step": round(mis["elapsed"] / mis["steps"] * 1e3, 3),
+                "value": round(mv, 2), "unit": "Mpath-bounces/s",
+                "mshadow_rays_per_s": round(mis["shadows"] / mis["elapsed"] / 1e6, 2),
+                "bounces_per_path": round(mis["bounces"] / max(mis["paths"], 1), 3),
+                "stage_ms": {**{k: round(v[0], 3) for k, v in mis["stage"].items()},
+                             **{k: round(v, 3) for k, v in (mis["extra_ms"] if mis["stage"] else {}).items()}},
+                "roofline": mis["roofline"],
+            }
+            if not args.no_cpu:
+                cpu = cpu_baseline(mis["scene"], mis["cfg"], mis["spp_full"], budget_s=6.0)
+                leg["cpu_baseline"] = cpu
+                leg["gpu_over_cpu"] = round(mv / cpu["value"], 1) if cpu["value"] else None
+                leg["gpu_over_cpu_8_threads"] = (round(mv / cpu["threads8"]["value"], 1)
+                                                 if cpu["threads8"]["value"] else None)
+            out["mis_cornell"] = leg
         print(json.dumps(out), flush=True)
-    r.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -12,7 +12,11 @@ root (RCCL over xGMI with the "nccl" backend; "gloo" on CPU in the tests).
 """
 from __future__ import annotations
 
-from typing import Tuple
+import os
+import socket
+import subprocess
+import sys
+from typing import List, Optional, Sequence, Tuple
 
 
 def split_range(n: int, parts: int, index: int) -> Tuple[int, int]:
@@ -55,3 +59,44 @@ def reduce_sum_to_root(accum, dst: int = 0):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM)
     return accum
+
+
+def spawn_local_ranks(script: str, argv: Sequence[str], nprocs: int, env: Optional[dict] = None,
+                      python: Optional[str] = None) -> int:
+    """Starts `nprocs` copies of `script argv...` as child processes, one rank each, with the
+    environment torch.distributed's env:// rendezvous reads (RANK, LOCAL_RANK, WORLD_SIZE,
+    LOCAL_WORLD_SIZE, MASTER_ADDR=127.0.0.1, MASTER_PORT=a free port), and waits for them.
+    Rank 0 inherits this process's stdout; the other ranks' stdout is discarded (stderr is kept).
+    Returns 0 when every rank exited with 0; otherwise the first failing rank's code, after
+    ending the ranks that were still running (by their own process ids).
+
+    The caller must not have touched the GPU: the children are fresh processes (no fork of an
+    initialised runtime, no exec from one), each of which selects its own device."""
+    if nprocs < 1:
+        raise ValueError("nprocs must be at least 1")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    base = dict(os.environ if env is None else env)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs: List[subprocess.Popen] = []
+    for rank in range(nprocs):
+        e = dict(base, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(nprocs),
+                 LOCAL_WORLD_SIZE=str(nprocs), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        out = None if rank == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([python or sys.executable, script, *argv], env=e, stdout=out))
+    rc = 0
+    pending = set(range(nprocs))
+    while pending:
+        for r in sorted(pending):
+            try:
+                code = procs[r].wait(timeout=0.2)
+            except subprocess.TimeoutExpired:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                for other in pending:  # a rank died: the others would wait in a collective for ever
+                    procs[other].terminate()
+    return rc

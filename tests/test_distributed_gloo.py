@@ -74,3 +74,24 @@ def test_two_ranks_add_up_to_one_process(mode, tmp_path, oracle):
     else:
         # (s0+s1+s2) + (s3+s4+s5) vs sequential: float association differs
         np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+
+
+def test_spawn_local_ranks(tmp_path):
+    """bench.py --gpus N starts its own ranks with spawn_local_ranks when it was not launched by
+    torch.distributed.run: every rank gets its rendezvous environment, only rank 0's stdout
+    comes through, and a failing rank makes the whole launch fail."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    child = os.path.join(here, "native", "rank_echo.py")
+    code = ("import sys; sys.path.insert(0, %r); from raytracer_amd import dist; "
+            "sys.exit(dist.spawn_local_ranks(%r, sys.argv[1:], 2))" % (os.path.dirname(here), child))
+    ok = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert ok.returncode == 0, ok.stderr
+    assert "noise from another rank" not in ok.stdout
+    lines = [l for l in ok.stdout.splitlines() if l.startswith("{")]  # (gloo itself prints a connection note)
+    assert len(lines) == 1
+    assert json.loads(lines[0]) == {"world": 2, "sum": 3.0, "local_rank": "0"}
+    bad = subprocess.run([sys.executable, "-c", code, "--fail-rank", "1"], capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 7
