@@ -71,7 +71,8 @@ def workloads():
         "sample1_diffuse": dict(scene=lambda: scenes.sphere_sky(glass=False), sky=1, width=512, height=512, spp=64),
         "sample3_mis_cornell": dict(scene=lambda: scenes.cornell(), sky=0, width=1024, height=1024, spp=256),
         "sample3_mis_cornell_4lights": dict(scene=lambda: scenes.cornell(lights=4), sky=0, width=1024, height=1024, spp=256),
-        "mesh_1m": dict(scene=lambda: scenes.terrain(707), sky=0, width=1920, height=1080, spp=256),
+        # the mesh goes through the OBJ path: written as OBJ + MTL and parsed by the host layer's load_obj
+        "mesh_1m": dict(scene=lambda: scenes.through_obj(scenes.terrain(707)), sky=0, width=1920, height=1080, spp=256),
         "soup150": dict(scene=lambda: scenes.soup(150, 3, seed=2), sky=1, width=1024, height=1024, spp=64),
         "soup3k": dict(scene=lambda: scenes.soup(3000, 3, seed=2), sky=1, width=1024, height=1024, spp=64),
         "terrain40": dict(scene=lambda: scenes.terrain(40), sky=0, width=1024, height=1024, spp=64),
@@ -260,6 +261,11 @@ def run_leg(args, workload, world, rank, local_rank, steps, warmup, profile, tor
     sc = wl["scene"]()
     r = Renderer(cfg)
     info = r.set_scene(sc)
+    native = world > 1 and args.reduce == "native"
+    if native:  # the library's own communicator: rank 0 makes the id, torch's group carries it
+        box = [Renderer.comm_create_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        r.comm_init(box[0], rank, world)
     # Two sum buffers, used in turn: the RCCL reduce of one step runs on RCCL's stream while the
     # next step renders into the other buffer.
     accums = [torch.zeros(H * W * 3, dtype=torch.float32, device="cuda") for _ in range(2 if world > 1 else 1)]
@@ -276,7 +282,9 @@ def run_leg(args, workload, world, rank, local_rank, steps, warmup, profile, tor
         buf = accums[b]
         buf.zero_()
         r.render(buf, spp, sample_base=base, seed=0x5EED, row0=row0, row1=row1, stream=stream)
-        if world > 1:  # bands are disjoint and zero elsewhere: one sum serves tiles and sample ranges
+        if native:
+            r.comm_reduce(buf, root=0, stream=stream)  # ordered on the render stream, after this step's render
+        elif world > 1:  # bands are disjoint and zero elsewhere: one sum serves tiles and sample ranges
             if args.backend == "nccl":
                 pending[b] = dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM, async_op=True)
             else:
@@ -297,7 +305,10 @@ def run_leg(args, workload, world, rank, local_rank, steps, warmup, profile, tor
     if world > 1:
         # Communicator set-up (RCCL builds its rings on the first collective) stays outside
         # the timed region whatever --warmup is.
-        if args.backend == "nccl":
+        if native:
+            r.comm_reduce(accums[0], root=0, stream=stream)
+            torch.cuda.synchronize()
+        elif args.backend == "nccl":
             dist.reduce(accums[0], dst=0, op=dist.ReduceOp.SUM)
         dist.barrier()
     for _ in range(warmup):
@@ -370,6 +381,10 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--no-mis", action="store_true", help="skip the second leg on the MIS Cornell scene")
+    ap.add_argument("--reduce", default="torch", choices=["torch", "native"],
+                    help="who issues the sum of the per-GPU buffers: torch.distributed (RCCL through torch), or the "
+                         "library's own exchange step (rtx_comm_reduce: RCCL loaded by librtx_hip.so, enqueued on "
+                         "the render stream)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + RTX_BENCH_SAME_GPU=1 rehearses the N>1 logic on one GPU (buffers are summed "
                          "through host memory); the real run uses nccl = RCCL")

@@ -41,7 +41,8 @@ typedef enum {
   RTX_ERR_HIP = -3,
   RTX_ERR_OUT_OF_MEMORY = -4,
   RTX_ERR_NO_SCENE = -5,
-  RTX_ERR_UNSUPPORTED = -6
+  RTX_ERR_UNSUPPORTED = -6,
+  RTX_ERR_COMM = -7
 } rtx_status;
 
 /* Surface enum, Material.h:4-9 (same values). */
@@ -222,6 +223,30 @@ int rtx_trace_closest_noalloc(rtx_ctx* ctx, const float* rays_host, size_t n, ui
 /* Scene::isOccluded (Scene.h:191-225) for n segments: occluded_out[i] in {0,1}. */
 int rtx_trace_occluded(rtx_ctx* ctx, const float* rays_host, const float* distance_host, size_t n,
                        uint8_t* occluded_out);
+
+/* Multi-GPU exchange step.  The reference renders with one OpenMP loop on one host
+ * (Raytracer.cpp:242) and has no counterpart.  Samples are independent and a sample's random
+ * stream depends only on (pixel, sample index, seed), so a render is spread over GPUs by giving
+ * every GPU -- one process and one context each -- its own range of sample indices (and, for
+ * large frames, its own band of rows); the per-GPU sum buffers are then added onto one root
+ * with a single RCCL reduce over xGMI, and the root calls rtx_resolve.
+ *   rtx_comm_create_id   on one rank: a fresh communicator id (ncclGetUniqueId); the caller
+ *                        carries its RTX_COMM_ID_BYTES bytes to the other ranks (a file, a socket);
+ *   rtx_comm_init        on every rank, with the same id: joins the communicator as `rank` of
+ *                        `world_size` (ncclCommInitRank on the context's GPU).  Blocks until all
+ *                        ranks have called it;
+ *   rtx_comm_reduce      on every rank: enqueues on `stream` the element-wise sum of all ranks'
+ *                        accum_dev buffers (width*height*3 floats) into the root's, in place
+ *                        (ncclReduce, ncclSum).  Ordered after the renders enqueued on that stream;
+ *   rtx_comm_destroy     leaves the communicator (rtx_destroy does it too).
+ * RCCL is loaded on first use; a host without it gets RTX_ERR_COMM from these calls only. */
+#define RTX_COMM_ID_BYTES 128
+int rtx_comm_create_id(char id_out[RTX_COMM_ID_BYTES]);
+int rtx_comm_init(rtx_ctx* ctx, const char id[RTX_COMM_ID_BYTES], int rank, int world_size);
+int rtx_comm_reduce(rtx_ctx* ctx, float* accum_dev, int root, void* stream);
+int rtx_comm_destroy(rtx_ctx* ctx);
+/* Waits for the work enqueued on `stream` of the context's GPU (for hosts that do not link HIP). */
+int rtx_stream_synchronize(rtx_ctx* ctx, void* stream);
 
 /* Known-answer hook for the device's generator (class Pcg, Sampler.h:11-42), all outputs host
  * arrays of n elements, any of them may be NULL: rand_out[i] = the i-th rand_pcg() of Pcg(seed),

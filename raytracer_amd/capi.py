@@ -96,8 +96,10 @@ SYMBOLS = [
     "rtx_render", "rtx_resolve", "rtx_trace_closest", "rtx_trace_occluded", "rtx_get_stats",
     "rtx_reset_stats", "rtx_set_profiling", "rtx_accum_alloc", "rtx_accum_free", "rtx_accum_clear",
     "rtx_accum_upload", "rtx_debug_pcg", "rtx_trace_closest_noalloc",
+    "rtx_comm_create_id", "rtx_comm_init", "rtx_comm_reduce", "rtx_comm_destroy", "rtx_stream_synchronize",
 ]
 
+COMM_ID_BYTES = 128
 _lib = None
 
 
@@ -134,6 +136,11 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rtx_accum_clear.argtypes = [vp, vp, vp]
     lib.rtx_accum_upload.argtypes = [vp, vp, vp, vp]
     lib.rtx_debug_pcg.argtypes = [vp, u32, u32, vp, vp, vp]
+    lib.rtx_comm_create_id.argtypes = [C.c_char_p]
+    lib.rtx_comm_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
+    lib.rtx_comm_reduce.argtypes = [vp, vp, C.c_int, vp]
+    lib.rtx_comm_destroy.argtypes = [vp]
+    lib.rtx_stream_synchronize.argtypes = [vp, vp]
     if path is None:
         _lib = lib
     return lib
@@ -328,6 +335,31 @@ class Renderer:
         self._check(self.lib.rtx_trace_occluded(self._ctx, _ptr(rays), _ptr(dist), rays.shape[0],
                                                 _ptr(out)))
         return out
+
+    # -- multi-GPU exchange step -----------------------------------------------------
+    @staticmethod
+    def comm_create_id(lib: Optional[C.CDLL] = None) -> bytes:
+        """A fresh communicator id (made on one rank, carried to the others by the caller)."""
+        lib = lib or load_library()
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        st = lib.rtx_comm_create_id(buf)
+        if st != 0:
+            raise RtxError(st, lib.rtx_last_error().decode())
+        return buf.raw
+
+    def comm_init(self, comm_id: bytes, rank: int, world_size: int):
+        assert len(comm_id) == COMM_ID_BYTES
+        self._check(self.lib.rtx_comm_init(self._ctx, comm_id, rank, world_size))
+
+    def comm_reduce(self, accum, root: int = 0, stream: int = 0):
+        """Enqueues the sum of every rank's buffer into the root's (RCCL reduce, in place)."""
+        self._check(self.lib.rtx_comm_reduce(self._ctx, _dev_ptr(accum), root, stream))
+
+    def comm_destroy(self):
+        self._check(self.lib.rtx_comm_destroy(self._ctx))
+
+    def stream_synchronize(self, stream: int = 0):
+        self._check(self.lib.rtx_stream_synchronize(self._ctx, stream))
 
     def debug_pcg(self, seed: int, n: int):
         """(rand_pcg draws, Uniform draws, pcg_hash(seed + i)) computed on the device."""

@@ -4,6 +4,8 @@
 // HIP only: there is no CPU path in this library.  Every entry point fails with
 // an error when no usable GPU is present.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <chrono>
@@ -126,6 +128,49 @@ struct DevBuf {
   }
 };
 
+// RCCL is loaded on first use (dlopen), so that single-GPU users of the library neither link nor
+// load it.  Only the five entry points the exchange step needs.
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error;
+};
+Rccl* rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.lib) break;
+    }
+    if (!r.lib) {
+      const char* e = dlerror();
+      r.error = std::string("cannot load librccl.so.1: ") + (e ? e : "unknown error");
+      return;
+    }
+    auto sym = [&](const char* n) {
+      void* p = dlsym(r.lib, n);
+      if (!p && r.error.empty()) r.error = std::string("librccl has no symbol ") + n;
+      return p;
+    };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.Reduce = reinterpret_cast<decltype(r.Reduce)>(sym("ncclReduce"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+  });
+  return r.error.empty() ? &r : nullptr;
+}
+int fail_rccl(ncclResult_t e, const char* what) {
+  Rccl* r = rccl();
+  g_last_error = std::string(what) + ": " + (r && r->GetErrorString ? r->GetErrorString(e) : "RCCL error");
+  return RTX_ERR_COMM;
+}
+
 struct StageTimer {
   std::vector<hipEvent_t> ev;  // pairs (start, stop)
   std::vector<int> kind;
@@ -169,6 +214,10 @@ struct rtx_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   DevBuf<uint4> stop4;  // per float of the image: the sample k_reduce_head stopped at
   unsigned long long overlap_min_samples = 0;  // chunks of at least this many samples split the sum
+
+  // multi-GPU exchange step (rtx_comm_*): this context's rank in an RCCL communicator
+  ncclComm_t comm = nullptr;
+  int comm_rank = -1, comm_world = 0;
 
   // stats
   rtx_stats stats{};
@@ -214,6 +263,10 @@ struct DeviceGuard {
 void free_ctx(rtx_ctx* c) {
   if (!c) return;
   DeviceGuard g(c->device);
+  if (c->comm) {
+    if (Rccl* r = rccl()) (void)r->CommDestroy(c->comm);
+    c->comm = nullptr;
+  }
   c->nodes.release(); c->tris.release();
   c->mat0.release(); c->mat1.release(); c->sph0.release(); c->sph1.release(); c->sph2.release(); c->sph3.release();
   c->box0.release(); c->box1.release(); c->pln0.release(); c->pln1.release();
@@ -1077,6 +1130,67 @@ static int impl_trace_occluded(rtx_ctx* c, const float* rays_host, const float* 
   return rc;
 }
 
+// ---- multi-GPU exchange step ----------------------------------------------------------------
+static int impl_comm_create_id(char* id_out) {
+  if (!id_out) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_comm_create_id: null argument");
+  Rccl* r = rccl();
+  if (!r) return fail(RTX_ERR_COMM, "rtx_comm_create_id: RCCL is not available on this host");
+  static_assert(RTX_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+  ncclUniqueId id;
+  ncclResult_t e = r->GetUniqueId(&id);
+  if (e != ncclSuccess) return fail_rccl(e, "ncclGetUniqueId");
+  std::memcpy(id_out, id.internal, RTX_COMM_ID_BYTES);
+  return RTX_OK;
+}
+static int impl_comm_init(rtx_ctx* c, const char* id_bytes, int rank, int world) {
+  if (!c || !id_bytes) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_comm_init: null argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_comm_init: bad rank or world size");
+  if (c->comm) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_comm_init: this context already has a communicator");
+  Rccl* r = rccl();
+  if (!r) return fail(RTX_ERR_COMM, "rtx_comm_init: RCCL is not available on this host");
+  DeviceGuard g(c->device);
+  if (!g.ok) return fail(RTX_ERR_HIP, "rtx_comm_init: hipSetDevice failed");
+  ncclUniqueId id;
+  std::memcpy(id.internal, id_bytes, RTX_COMM_ID_BYTES);
+  ncclResult_t e = r->CommInitRank(&c->comm, world, id, rank);
+  if (e != ncclSuccess) {
+    c->comm = nullptr;
+    return fail_rccl(e, "ncclCommInitRank");
+  }
+  c->comm_rank = rank;
+  c->comm_world = world;
+  return RTX_OK;
+}
+static int impl_comm_reduce(rtx_ctx* c, float* accum_dev, int root, void* stream) {
+  if (!c || !accum_dev) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_comm_reduce: null argument");
+  if (!c->comm) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_comm_reduce: no communicator (rtx_comm_init)");
+  if (root < 0 || root >= c->comm_world) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_comm_reduce: bad root");
+  DeviceGuard g(c->device);
+  if (!g.ok) return fail(RTX_ERR_HIP, "rtx_comm_reduce: hipSetDevice failed");
+  const size_t n = (size_t)c->cfg.width * c->cfg.height * 3;
+  ncclResult_t e = rccl()->Reduce(accum_dev, accum_dev, n, ncclFloat, ncclSum, root, c->comm, (hipStream_t)stream);
+  if (e != ncclSuccess) return fail_rccl(e, "ncclReduce");
+  return RTX_OK;
+}
+static int impl_comm_destroy(rtx_ctx* c) {
+  if (!c) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_comm_destroy: null argument");
+  if (!c->comm) return RTX_OK;
+  DeviceGuard g(c->device);
+  ncclResult_t e = rccl()->CommDestroy(c->comm);
+  c->comm = nullptr;
+  c->comm_rank = -1;
+  c->comm_world = 0;
+  if (e != ncclSuccess) return fail_rccl(e, "ncclCommDestroy");
+  return RTX_OK;
+}
+static int impl_stream_sync(rtx_ctx* c, void* stream) {
+  if (!c) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_stream_synchronize: null argument");
+  DeviceGuard g(c->device);
+  if (!g.ok) return fail(RTX_ERR_HIP, "rtx_stream_synchronize: hipSetDevice failed");
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return RTX_OK;
+}
+
 static int impl_debug_pcg(rtx_ctx* c, uint32_t seed, uint32_t n, uint32_t* rand_out, float* uniform_out,
                           uint32_t* hash_out) {
   if (!c) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_debug_pcg: null argument");
@@ -1201,6 +1315,21 @@ int rtx_trace_closest_noalloc(rtx_ctx* c, const float* rays_host, size_t n, uint
 }
 int rtx_trace_occluded(rtx_ctx* c, const float* rays_host, const float* distance_host, size_t n, uint8_t* occluded_out) {
   return guarded("rtx_trace_occluded", [&] { return impl_trace_occluded(c, rays_host, distance_host, n, occluded_out); });
+}
+int rtx_comm_create_id(char id_out[RTX_COMM_ID_BYTES]) {
+  return guarded("rtx_comm_create_id", [&] { return impl_comm_create_id(id_out); });
+}
+int rtx_comm_init(rtx_ctx* c, const char id[RTX_COMM_ID_BYTES], int rank, int world_size) {
+  return guarded("rtx_comm_init", [&] { return impl_comm_init(c, id, rank, world_size); });
+}
+int rtx_comm_reduce(rtx_ctx* c, float* accum_dev, int root, void* stream) {
+  return guarded("rtx_comm_reduce", [&] { return impl_comm_reduce(c, accum_dev, root, stream); });
+}
+int rtx_comm_destroy(rtx_ctx* c) {
+  return guarded("rtx_comm_destroy", [&] { return impl_comm_destroy(c); });
+}
+int rtx_stream_synchronize(rtx_ctx* c, void* stream) {
+  return guarded("rtx_stream_synchronize", [&] { return impl_stream_sync(c, stream); });
 }
 int rtx_debug_pcg(rtx_ctx* c, uint32_t seed, uint32_t n, uint32_t* rand_out, float* uniform_out, uint32_t* hash_out) {
   return guarded("rtx_debug_pcg", [&] { return impl_debug_pcg(c, seed, n, rand_out, uniform_out, hash_out); });

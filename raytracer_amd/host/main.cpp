@@ -4,7 +4,17 @@
 //
 //   rt_host [--obj FILE] [--width W] [--height H] [--spp N] [--passes P] [--sky]
 //           [--out PREFIX] [--checkpoint FILE] [--resume FILE] [--parse-only]
-//           [--pfm-to-exr IN OUT]
+//           [--pfm-to-exr IN OUT] [--dump-mesh FILE] [--gpus N]
+//
+// --gpus N renders on N GPUs of this host: the program starts N copies of itself, one rank per
+// GPU (before it has touched a GPU itself), every rank renders its share of each pass's samples,
+// the sums meet on rank 0 through the library's RCCL reduce, and rank 0 writes the image.
+// --comm goes through the same start-up, communicator and reduce with a single rank as well
+// (a one-GPU host can rehearse everything but the wire: RCCL refuses two ranks on one GPU).
+//
+// --dump-mesh (with --obj, no device needed) writes what load_mesh produced as a binary file:
+// two little-endian uint64 (triangles, materials), then 9 floats per triangle, then one uint32
+// material slot per triangle -- the arrays rtx_set_scene takes.
 //
 // --checkpoint writes the per-pixel sums and the sample count after the last pass; --resume
 // starts from such a file and goes on with the next sample index, so that two runs of P passes
@@ -16,9 +26,14 @@
 // With --obj, material slots are overridden the way Raytracer.cpp:163-171 does when the
 // file has at least 8 materials.
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+
+#include <spawn.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include "rt_host.hpp"
 
@@ -41,11 +56,54 @@ static Mesh* procedural_cornell() {
   return m;
 }
 
+extern char** environ;
+
+// Starts `world` copies of this program, rank r with "--rank r --world N --rendezvous FILE"
+// appended, and waits for them; a failing rank ends the others.  No GPU call is made here.
+static int spawn_ranks(int argc, char** argv, int world, const std::string& id_file) {
+  std::remove(id_file.c_str());
+  std::vector<pid_t> pids;
+  for (int r = 0; r < world; r++) {
+    std::vector<std::string> args(argv, argv + argc);
+    args.insert(args.end(), {"--rank", std::to_string(r), "--world", std::to_string(world), "--rendezvous", id_file});
+    std::vector<char*> av;
+    for (std::string& a : args) av.push_back(&a[0]);
+    av.push_back(nullptr);
+    pid_t pid = 0;
+    if (posix_spawn(&pid, "/proc/self/exe", nullptr, nullptr, av.data(), environ) != 0) {
+      std::fprintf(stderr, "error: cannot start rank %d\n", r);
+      for (pid_t p : pids) kill(p, SIGTERM);
+      return 1;
+    }
+    pids.push_back(pid);
+  }
+  int rc = 0;
+  size_t left = pids.size();
+  while (left > 0) {
+    int status = 0;
+    const pid_t p = wait(&status);
+    if (p < 0) break;
+    left--;
+    const int code = WIFEXITED(status) ? WEXITSTATUS(status) : 128 + WTERMSIG(status);
+    if (code != 0 && rc == 0) {
+      rc = code;
+      for (pid_t q : pids)
+        if (q != p) kill(q, SIGTERM);  // the others would wait in the collective for ever
+    }
+  }
+  std::remove(id_file.c_str());
+  return rc;
+}
+
 int main(int argc, char** argv) {
   std::string obj, out = "render";
+  int gpus = 1;
+  bool force_comm = false;
+  Ranks rk;
+  std::string rendezvous;
   uint32_t width = 800, height = 800, spp = 16, passes = 1;
   bool sky = false, parse_only = false;
-  std::string pfm_in, exr_out, resume, checkpoint;
+  std::string pfm_in, exr_out, resume, checkpoint, dump_mesh;
   for (int i = 1; i < argc; i++) {
     auto next = [&](const char* name) -> const char* {
       if (i + 1 >= argc) {
@@ -64,6 +122,12 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--parse-only")) parse_only = true;
     else if (!std::strcmp(argv[i], "--resume")) resume = next("--resume");
     else if (!std::strcmp(argv[i], "--checkpoint")) checkpoint = next("--checkpoint");
+    else if (!std::strcmp(argv[i], "--dump-mesh")) dump_mesh = next("--dump-mesh");
+    else if (!std::strcmp(argv[i], "--gpus")) gpus = std::atoi(next("--gpus"));
+    else if (!std::strcmp(argv[i], "--comm")) force_comm = true;
+    else if (!std::strcmp(argv[i], "--rank")) rk.rank = std::atoi(next("--rank"));
+    else if (!std::strcmp(argv[i], "--world")) rk.world = std::atoi(next("--world"));
+    else if (!std::strcmp(argv[i], "--rendezvous")) rendezvous = next("--rendezvous");
     else if (!std::strcmp(argv[i], "--pfm-to-exr")) {
       pfm_in = next("--pfm-to-exr");
       exr_out = next("--pfm-to-exr");
@@ -73,12 +137,40 @@ int main(int argc, char** argv) {
       return 2;
     }
   }
+  if (gpus < 1 || rk.world < 1 || rk.rank < 0 || rk.rank >= rk.world) {
+    std::cerr << "bad --gpus / --rank / --world\n";
+    return 2;
+  }
+  if ((gpus > 1 || force_comm) && rendezvous.empty())  // the parent: it only starts the ranks
+    return spawn_ranks(argc, argv, gpus, out + ".commid." + std::to_string((long)getpid()));
+  const bool root = rk.rank == 0;
   try {
     if (!pfm_in.empty()) {
       // Image writer only (no device needed): a float image in, the saveEXR file out.
       Img img(1, 1);
       if (!img.loadPFM(pfm_in.c_str())) throw Error("cannot read " + pfm_in);
       if (!img.saveEXR(exr_out.c_str())) throw Error("cannot write " + exr_out);
+      return 0;
+    }
+    if (!dump_mesh.empty()) {
+      if (obj.empty()) throw Error("--dump-mesh needs --obj");
+      Mesh* m = load_obj(obj);
+      FILE* f = std::fopen(dump_mesh.c_str(), "wb");
+      if (!f) throw Error("cannot write " + dump_mesh);
+      const uint64_t head[2] = {m->triangles.size(), m->materials.size()};
+      bool ok = std::fwrite(head, sizeof(head), 1, f) == 1;
+      for (const Triangle& t : m->triangles) {
+        const float v[9] = {t.a.x, t.a.y, t.a.z, t.b.x, t.b.y, t.b.z, t.c.x, t.c.y, t.c.z};
+        ok = ok && std::fwrite(v, sizeof(v), 1, f) == 1;
+      }
+      for (unsigned idx : m->material_idxs) {
+        const uint32_t v = idx;
+        ok = ok && std::fwrite(&v, 4, 1, f) == 1;
+      }
+      ok = (std::fclose(f) == 0) && ok;
+      if (!ok) throw Error("cannot write " + dump_mesh);
+      std::printf("triangles %zu materials %zu\n", m->triangles.size(), m->materials.size());
+      delete m;
       return 0;
     }
     if (parse_only) {
@@ -96,6 +188,8 @@ int main(int argc, char** argv) {
     }
     rtx_config cfg = default_config(width, height);
     cfg.sky = sky ? 1 : 0;
+    const bool ranks = !rendezvous.empty();  // started by spawn_ranks: one GPU per rank, sums meet on rank 0
+    if (ranks) cfg.device = rk.rank;
 
     auto t1 = std::chrono::high_resolution_clock::now();
     Scene scene(cfg);
@@ -117,20 +211,27 @@ int main(int argc, char** argv) {
     scene.spheres.push_back(Sphere(Vec3(-0.5f, 0.302f, 0.55f), 0.3f));
     scene.spheres[0].material = specularMat;
     scene.commit();
+    if (ranks) comm_join(scene, rk, rendezvous);
     float seconds = std::chrono::duration<float>(std::chrono::high_resolution_clock::now() - t1).count();
-    std::printf("Scene built in %f seconds (%zu triangles, %zu materials)\n", seconds, mesh->triangles.size(),
-                mesh->materials.size());
+    if (root)
+      std::printf("Scene built in %f seconds (%zu triangles, %zu materials%s)\n", seconds, mesh->triangles.size(),
+                  mesh->materials.size(), ranks ? (", " + std::to_string(rk.world) + " ranks").c_str() : "");
 
     Img img(width, height);
     clear(img, scene);
     if (!resume.empty()) {
+      // every rank learns the sample count; only rank 0's buffer carries the sums on
       load_checkpoint(img, scene, resume.c_str());
-      std::printf("Resumed %s at %u samples per pixel\n", resume.c_str(), img.sample_count);
+      if (root) std::printf("Resumed %s at %u samples per pixel\n", resume.c_str(), img.sample_count);
     }
     auto t0 = std::chrono::high_resolution_clock::now();
     for (uint32_t p = 0; p < passes; p++) {
       auto tp = std::chrono::high_resolution_clock::now();
-      render(img, scene, spp);
+      if (ranks)
+        render_ranks(img, scene, rk, spp);
+      else
+        render(img, scene, spp);
+      if (!root) continue;
       float s = std::chrono::duration<float>(std::chrono::high_resolution_clock::now() - tp).count();
       // the reference's per-pass report (Raytracer.cpp:281-285, 322-323)
       std::printf("Took %f seconds\nCast %llu rays\n%f samples per second \n", s,
@@ -138,9 +239,14 @@ int main(int argc, char** argv) {
       float total = std::chrono::duration<float>(std::chrono::high_resolution_clock::now() - t0).count();
       std::printf("Accumulated %u samples per pixel over %f seconds\n\n", img.sample_count, total);
     }
-    if (!checkpoint.empty()) save_checkpoint(img, scene, checkpoint.c_str());
     rtx_stats st;
     check(rtx_get_stats(scene.ctx(), &st), "rtx_get_stats");
+    if (!root) {
+      std::printf("rank %d: paths %llu, path-bounces %llu, shadow rays %llu\n", rk.rank, (unsigned long long)st.paths,
+                  (unsigned long long)st.bounces, (unsigned long long)st.shadow_rays);
+      return 0;
+    }
+    if (!checkpoint.empty()) save_checkpoint(img, scene, checkpoint.c_str());
     std::printf("paths %llu, path-bounces %llu, shadow rays %llu\n", (unsigned long long)st.paths,
                 (unsigned long long)st.bounces, (unsigned long long)st.shadow_rays);
     if (!img.savePFM((out + ".pfm").c_str()) || !img.savePPM((out + ".ppm").c_str()) ||

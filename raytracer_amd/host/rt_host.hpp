@@ -15,6 +15,7 @@
 // Errors are reported by exceptions carrying rtx_last_error() (the reference
 // calls exit(1), Scene.h:66).
 #pragma once
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -26,6 +27,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rtx_capi.h"
@@ -651,6 +653,71 @@ inline void load_checkpoint(Img& img, Scene& scene, const char* path) {
   check(rtx_accum_upload(scene.ctx(), scene.accum(), &sums.pixels[0].x, nullptr), "rtx_accum_upload");
   img.sample_count = (uint32_t)count;
   check(rtx_resolve(scene.ctx(), scene.accum(), img.sample_count, &img.pixels[0].x, nullptr), "rtx_resolve");
+}
+
+// ---- several GPUs: one process per GPU, one exchange step ----------------------------------------
+// The reference renders with one OpenMP loop (Raytracer.cpp:242); here every rank (process) owns
+// one GPU and one Scene, takes its share of each pass's sample indices, and the per-GPU sums
+// are added onto rank 0 by the library's RCCL reduce (rtx_comm_reduce).  Rank 0 keeps the
+// running total in its buffer; the other ranks' buffers hold one pass at a time.
+struct Ranks {
+  int rank = 0, world = 1;
+};
+
+// Share `index` of n items cut into `parts` near-equal contiguous shares (the first n % parts
+// get one more): {first, count}.
+inline void split_range(uint32_t n, int parts, int index, uint32_t& first, uint32_t& count) {
+  const uint32_t q = n / (uint32_t)parts, r = n % (uint32_t)parts;
+  first = (uint32_t)index * q + ((uint32_t)index < r ? (uint32_t)index : r);
+  count = q + ((uint32_t)index < r ? 1u : 0u);
+}
+
+// Joins the ranks' communicator.  Rank 0 makes the id and publishes it as `id_file` (written
+// under another name and renamed, so a reader never sees half of it); the others wait for the file.
+inline void comm_join(Scene& scene, const Ranks& rk, const std::string& id_file, double timeout_s = 120.0) {
+  char id[RTX_COMM_ID_BYTES];
+  if (rk.rank == 0) {
+    check(rtx_comm_create_id(id), "rtx_comm_create_id");
+    const std::string tmp = id_file + ".tmp";
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f || std::fwrite(id, 1, sizeof(id), f) != sizeof(id) || std::fclose(f) != 0 ||
+        std::rename(tmp.c_str(), id_file.c_str()) != 0)
+      throw Error("cannot write " + id_file);
+  } else {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      FILE* f = std::fopen(id_file.c_str(), "rb");
+      if (f) {
+        const size_t got = std::fread(id, 1, sizeof(id), f);
+        std::fclose(f);
+        if (got == sizeof(id)) break;
+      }
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+        throw Error("timed out waiting for " + id_file);
+      std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    }
+  }
+  check(rtx_comm_init(scene.ctx(), id, rk.rank, rk.world), "rtx_comm_init");
+}
+
+// One pass of `spp` samples per pixel spread over the ranks: sample indices
+// img.sample_count .. +spp-1 are cut into contiguous shares, every rank renders its own, and the
+// sums meet on rank 0, whose img.pixels gets the new mean.  The union of the shares is what
+// render() renders on one GPU; only the order of the float additions differs.
+inline void render_ranks(Img& img, Scene& scene, const Ranks& rk, uint32_t spp = 1, uint64_t seed = 0x5EED,
+                         Vec3 pos = Vec3()) {
+  const float off[3] = {pos.x, pos.y, pos.z};
+  uint32_t first, count;
+  split_range(spp, rk.world, rk.rank, first, count);
+  if (rk.rank != 0) check(rtx_accum_clear(scene.ctx(), scene.accum(), nullptr), "rtx_accum_clear");
+  if (count)
+    check(rtx_render(scene.ctx(), scene.accum(), count, img.sample_count + first, seed, off, 0, 0, nullptr),
+          "rtx_render");
+  check(rtx_comm_reduce(scene.ctx(), scene.accum(), 0, nullptr), "rtx_comm_reduce");
+  check(rtx_stream_synchronize(scene.ctx(), nullptr), "rtx_stream_synchronize");
+  img.sample_count += spp;
+  if (rk.rank == 0)
+    check(rtx_resolve(scene.ctx(), scene.accum(), img.sample_count, &img.pixels[0].x, nullptr), "rtx_resolve");
 }
 
 }  // namespace rt

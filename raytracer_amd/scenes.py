@@ -286,3 +286,61 @@ def random_rays(n, seed=7, origin_box=((-1.2, -0.2, -1.2), (1.2, 2.2, 3.2)), uni
     if not unit:
         d *= rng.uniform(0.5, 2.0, (n, 1))
     return np.concatenate([o, d], 1).astype(np.float32)
+
+
+def write_obj(scene: SceneData, obj_path: str, num_slots: int = 8) -> None:
+    """Writes the scene's triangles as a Wavefront OBJ with an MTL of `num_slots` materials
+    (m0, m1, ...: one slot per material index, the numbering load_mesh derives from the MTL,
+    Scene.h:55-115).  Vertices are shared where their coordinates are identical; coordinates
+    are printed with nine significant digits, which a float32 survives unchanged.  Faces keep
+    the triangle order and each triangle's vertex order."""
+    import os
+    tris = scene.triangles.reshape(-1, 3, 3)
+    verts, inverse = np.unique(tris.reshape(-1, 3), axis=0, return_inverse=True)
+    faces = inverse.reshape(-1, 3) + 1
+    mtl_name = os.path.splitext(os.path.basename(obj_path))[0] + ".mtl"
+    with open(os.path.join(os.path.dirname(obj_path), mtl_name), "w") as f:
+        for i in range(max(num_slots, int(scene.material_index.max()) + 1 if len(scene.material_index) else 0)):
+            f.write(f"newmtl m{i}\nKd 0.5 0.5 0.5\n")
+    with open(obj_path, "w") as f:
+        f.write(f"mtllib {mtl_name}\n")
+        np.savetxt(f, verts, fmt="v %.9g %.9g %.9g")
+        mi = scene.material_index
+        # runs of equal material: one usemtl line per run
+        starts = np.concatenate([[0], np.nonzero(np.diff(mi.astype(np.int64)))[0] + 1, [len(mi)]])
+        for a, b in zip(starts[:-1], starts[1:]):
+            f.write(f"usemtl m{int(mi[a])}\n")
+            np.savetxt(f, faces[a:b], fmt="f %d %d %d")
+
+
+def read_mesh_dump(path: str):
+    """(triangles (n, 9) float32, material slots (n,) uint32, number of materials) from the
+    binary file rt_host --dump-mesh writes."""
+    with open(path, "rb") as f:
+        ntri, nmat = (int(x) for x in np.frombuffer(f.read(16), "<u8"))
+        tris = np.frombuffer(f.read(36 * ntri), "<f4").reshape(ntri, 9)
+        mats = np.frombuffer(f.read(4 * ntri), "<u4")
+    assert len(mats) == ntri
+    return tris.copy(), mats.copy(), nmat
+
+
+def through_obj(scene: SceneData, workdir=None) -> SceneData:
+    """The same scene with its mesh taken through the OBJ path: written as OBJ + MTL, parsed by
+    the C++ host layer's load_obj (raytracer_amd/host, the replacement of Scene::load_mesh,
+    Scene.h:55-115) and read back.  Raises if the file round trip changed a bit."""
+    import os
+    import subprocess
+    import tempfile
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host", "rt_host")
+    if not os.path.exists(exe):
+        raise FileNotFoundError(f"{exe} not built (make -C raytracer_amd/csrc host)")
+    with tempfile.TemporaryDirectory(dir=workdir) as d:
+        obj, dump = os.path.join(d, "mesh.obj"), os.path.join(d, "mesh.bin")
+        write_obj(scene, obj)
+        subprocess.check_call([exe, "--obj", obj, "--dump-mesh", dump], stdout=subprocess.DEVNULL)
+        tris, mats, _ = read_mesh_dump(dump)
+    if not (np.array_equal(tris.view(np.uint32), scene.triangles.view(np.uint32)) and
+            np.array_equal(mats, scene.material_index)):
+        raise ValueError("the OBJ round trip changed the mesh")
+    return SceneData(tris, mats, scene.materials, scene.spheres, name=scene.name + "_obj", boxes=scene.boxes,
+                     planes=scene.planes)
