@@ -245,7 +245,12 @@ def build_roofline(workload, stage, fused):
 def run_leg(args, workload, world, rank, local_rank, steps, warmup, profile, torch, dist):
     """Renders `workload` warmup + steps times; returns the measurements of this rank's view."""
     from raytracer_amd.capi import Config, Renderer
-    wl = workloads()[workload]
+    if workload.startswith("soup") and workload not in workloads():  # soupN: N random triangles, any N
+        from raytracer_amd import scenes
+        n = int(workload[4:])
+        wl = dict(scene=lambda: scenes.soup(n, 3, seed=2), sky=1, width=1024, height=1024, spp=64)
+    else:
+        wl = workloads()[workload]
     W = args.width or wl["width"]
     H = args.height or wl["height"]
     spp_full = args.spp or wl["spp"]

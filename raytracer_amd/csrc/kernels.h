@@ -138,6 +138,9 @@ struct RenderParams {
   uint32_t seed32;       // seed folded to 32 bits
 };
 
+#ifndef RTX_FULL_RECORD_READS
+#define RTX_FULL_RECORD_READS 1
+#endif
 // Where the traversal kernels read the BVH and the triangles from: the global
 // arrays of SceneDev, or a copy of them in LDS (scenes of a few hundred
 // triangles: every lane's node and triangle fetches then cost an LDS read
@@ -145,7 +148,15 @@ struct RenderParams {
 struct Geom {
   const float4* nodes;
   const float4* tris;  // four float4 per triangle slot
+  uint32_t stride;     // float4 between consecutive records: 4 in global memory; kLdsRecordStride in the LDS copy
 };
+// Records in the LDS copy are 80 bytes apart, not 64: a 16-byte read of record i then starts at
+// bank 20 i mod 64, sixteen different places for sixteen consecutive records, where 64-byte
+// records offer four (lanes that read different records collide on the banks otherwise).
+#ifndef RTX_LDS_RECORD_STRIDE
+#define RTX_LDS_RECORD_STRIDE 5
+#endif
+constexpr uint32_t kLdsRecordStride = RTX_LDS_RECORD_STRIDE;
 
 // How a traversal kernel reads the tree.
 enum TraceMode {
@@ -182,18 +193,21 @@ __device__ __forceinline__ Geom global_geom(const SceneDev& sc) {
   Geom g;
   g.nodes = sc.nodes;
   g.tris = sc.tris;
+  g.stride = 4;
   return g;
 }
 // Copies [nodes | triangle records] into `dst` (LDS) with the whole block and
 // returns the view; ends with a barrier, so every thread of the block must call it.
 __device__ __forceinline__ Geom stage_geom_lds(const SceneDev& sc, float4* dst, int tid, int nthreads) {
   const uint32_t nn = 4 * sc.num_nodes, nt = 4 * sc.num_tris;
-  for (uint32_t k = tid; k < nn; k += nthreads) dst[k] = sc.nodes[k];
-  for (uint32_t k = tid; k < nt; k += nthreads) dst[nn + k] = sc.tris[k];
+  float4* const tdst = dst + kLdsRecordStride * sc.num_nodes;
+  for (uint32_t k = tid; k < nn; k += nthreads) dst[(k >> 2) * kLdsRecordStride + (k & 3u)] = sc.nodes[k];
+  for (uint32_t k = tid; k < nt; k += nthreads) tdst[(k >> 2) * kLdsRecordStride + (k & 3u)] = sc.tris[k];
   __syncthreads();
   Geom g;
   g.nodes = dst;
-  g.tris = dst + nn;
+  g.tris = tdst;
+  g.stride = kLdsRecordStride;
   return g;
 }
 
@@ -219,8 +233,13 @@ __device__ __forceinline__ float tri_intersect(f3 a, f3 ba, f3 ca, f3 o, f3 d) {
 // computed on the host with the same float operations (no contraction on either
 // side), so the lanes do not recompute it; it shares the record's 64-byte line.
 __device__ __forceinline__ float tri_test(const Geom& g, uint32_t slot, f3 o, f3 d, uint32_t& prim) {
-  const float4* r = g.tris + 4 * (size_t)slot;
+  const float4* r = g.tris + g.stride * (size_t)slot;
   float4 A = r[0], B = r[1], C = r[2], N = r[3];
+#if RTX_FULL_RECORD_READS
+  // keeps the reads 16 bytes wide: the unused fourth components would otherwise turn them into
+  // 12-byte LDS reads, which take twice the LDS cycles of a 16-byte one
+  asm volatile("" ::"v"(B.w), "v"(C.w), "v"(N.w));
+#endif
   prim = __float_as_uint(A.w);
   return tri_intersect_n(mk3(A.x, A.y, A.z), mk3(B.x, B.y, B.z), mk3(C.x, C.y, C.z), mk3(N.x, N.y, N.z), o, d);
 }
@@ -425,7 +444,7 @@ struct ClosestHit {
 
 // One two-child node of a closest-hit walk: the nearer child next, the other pushed.
 __device__ __forceinline__ void closest_node_step(const Geom& g, const Stack& stk, Walk& w, const ClosestHit& best) {
-  const float4* nd = g.nodes + 4 * (size_t)w.cur;
+  const float4* nd = g.nodes + g.stride * (size_t)w.cur;
   float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
   float tn0, tn1;
   bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, w.inv, w.add_lo, w.add_hi, best.t, tn0);
@@ -449,7 +468,7 @@ __device__ __forceinline__ void closest_nodes(const Geom& g, const Stack& stk, W
   if (MODE == kGlobalBvh4) {
     while (w.cur >= 0) {
       int4 refs;
-      const float4* nd = g.nodes + 4 * (size_t)w.cur;
+      const float4* nd = g.nodes + g.stride * (size_t)w.cur;
       Node4Test nt = test_node4(nd[0], nd[1], nd[2], nd[3], w.o, w.inv, best.t, refs);
       float t0 = nt.hit[0] ? nt.tn[0] : INFINITY, t1 = nt.hit[1] ? nt.tn[1] : INFINITY;
       float t2 = nt.hit[2] ? nt.tn[2] : INFINITY, t3 = nt.hit[3] ? nt.tn[3] : INFINITY;
@@ -489,7 +508,7 @@ __device__ __forceinline__ void any_nodes(const Geom& g, const Stack& stk, Walk&
   if (MODE == kGlobalBvh4) {
     while (w.cur >= 0) {
       int4 refs;
-      const float4* nd = g.nodes + 4 * (size_t)w.cur;
+      const float4* nd = g.nodes + g.stride * (size_t)w.cur;
       Node4Test nt = test_node4(nd[0], nd[1], nd[2], nd[3], w.o, w.inv, tfar, refs);
       int next = kTraversalDone;
       if (nt.hit[3]) next = refs.w;
@@ -509,7 +528,7 @@ __device__ __forceinline__ void any_nodes(const Geom& g, const Stack& stk, Walk&
     }
   } else {
     while (w.cur >= 0) {
-      const float4* nd = g.nodes + 4 * (size_t)w.cur;
+      const float4* nd = g.nodes + g.stride * (size_t)w.cur;
       float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
       float tn0, tn1;
       bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, w.inv, w.add_lo, w.add_hi, tfar, tn0);
@@ -826,7 +845,7 @@ __device__ __forceinline__ void hit_surface(const SceneDev& sc, const Geom& g, u
     emission = m.w;
     surface = sc.sph2[i];
   } else {
-    float4 B = g.tris[4 * (size_t)id + 1], N = g.tris[4 * (size_t)id + 3];
+    float4 B = g.tris[g.stride * (size_t)id + 1], N = g.tris[g.stride * (size_t)id + 3];
     n = vnormalized(mk3(N.x, N.y, N.z));
     uint32_t mi = __float_as_uint(B.w);
     float4 m = sc.mat0[mi];

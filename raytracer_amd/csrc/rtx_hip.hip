@@ -57,7 +57,10 @@ constexpr uint32_t kDefaultResultMiB = 8192;     // per-sample result buffer bud
 constexpr uint32_t kSegmentTarget = 8192;        // aim for this many slots per queue segment
 constexpr uint32_t kMaxSegments = 512;
 constexpr int kTraceBlock = 128;                 // threads per block of the traversal kernels
-constexpr size_t kLdsSceneMaxBytes = 16 * 1024;  // stage BVH + triangles in LDS up to this size
+constexpr size_t kLdsSceneMaxBytes = 24 * 1024;  // stage BVH + triangles in LDS up to this size (80-byte LDS records: about 200
+                                                 // triangles).  Measured crossover with the four-wide tree in global memory on random soups
+                                                 // (tools/lds_vs_global.sh): LDS 1.67x faster at 100 triangles, 1.18x at 150, equal at 220,
+                                                 // 0.62x at 300
 constexpr size_t kLdsLaunchMaxBytes = 64 * 1024;  // dynamic LDS a launch may ask for without raising the kernel's limit
 constexpr int kWideLdsStack = 16;                // LDS stack entries per lane for the four-child tree
 constexpr int kFinishBlock = 64;
@@ -423,7 +426,9 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
   // Larger scenes stream their nodes from L2/HBM: four-child quantised nodes (two levels per
   // 64-byte fetch).  Leaves hold at most 2 triangles in both forms (a box test costs about a
   // third of a triangle test; measured best on the 1M-triangle mesh as well).
-  const bool small_scene = s->num_triangles > 0 && s->num_triangles * (64 + 32 + 8) <= kLdsSceneMaxBytes;
+  size_t lds_scene_max = kLdsSceneMaxBytes;
+  if (const char* e = std::getenv("RTX_LDS_SCENE_MAX_KB")) lds_scene_max = (size_t)std::atoi(e) * 1024;  // (tuning runs)
+  const bool small_scene = s->num_triangles > 0 && s->num_triangles * (16 * rtx::kLdsRecordStride * 3 / 2 + 8) <= lds_scene_max;
   rtx::FlatBvh bvh;
   rtx::build_bvh(s->triangles, s->num_triangles, 2u, small_scene ? 2u : 4u, bvh);
   // Stack: two-child trees keep all of it in LDS; the wide tree keeps kWideLdsStack entries
@@ -581,10 +586,10 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
   for (const float4& m : sp1) emits = emits || m.w > 0.0f;
   d.carries_colour = emits ? 1 : 0;
   c->stack_entries = stack_entries;
-  c->lds_scene_bytes = (nodes.size() + 4 * nt) * sizeof(float4);
+  c->lds_scene_bytes = (nodes.size() / 4 + nt) * rtx::kLdsRecordStride * sizeof(float4);  // as stage_geom_lds lays it out
   if (bvh.width == 4)
     c->trace_mode = rtx::kGlobalBvh4;
-  else if (nt > 0 && c->lds_scene_bytes <= kLdsSceneMaxBytes && !std::getenv("RTX_NO_LDS_SCENE") &&  // (test hook)
+  else if (nt > 0 && c->lds_scene_bytes <= lds_scene_max && !std::getenv("RTX_NO_LDS_SCENE") &&  // (test hook)
            (size_t)stack_entries * kTraceBlock * sizeof(int) + c->lds_scene_bytes <= kLdsLaunchMaxBytes)
     c->trace_mode = rtx::kLdsBvh2;  // (a very deep small tree leaves the LDS to the stacks and stays in global memory)
   else

@@ -226,8 +226,12 @@ def test_sum_beside_the_drain_kernel_keeps_the_bits(finish_paths, rtx_lib, monke
         assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
         assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
         assert out[0][2] == out[1][2]
-        if finish_paths != 0:
+        if finish_paths == 1 << 20:
             assert out[0][3] > out[1][3]       # the split sum really ran (two more launches per chunk)
+        elif finish_paths != 0:
+            # with a threshold of 4096 paths the drain kernel runs only if a snapshot of the queue lands
+            # between 4096 and 0 paths left, which depends on timing: the split sum may or may not run
+            assert out[0][3] >= out[1][3]
 
 
 @pytest.mark.parametrize("inside", [True, False], ids=["triangle_inside_sphere", "triangle_far_away"])

@@ -7,7 +7,7 @@ import subprocess
 import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-S",
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-S",
        "--cuda-device-only", "-o", "/tmp/rtx_resources.s", os.path.join(root, "raytracer_amd/csrc/rtx_hip.hip"),
        "-Rpass-analysis=kernel-resource-usage"] + sys.argv[1:]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
