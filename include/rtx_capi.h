@@ -191,7 +191,11 @@ int rtx_get_scene_info(rtx_ctx* ctx, rtx_scene_info* out);
  * `pos` added to every ray origin (Raytracer.cpp:250); NULL = (0,0,0).
  * The per-path random stream depends only on (pixel, sample index, seed), so
  * disjoint sample ranges rendered on different GPUs add up to the same image as
- * one GPU rendering the union.  Returns after the work has finished on `stream`
+ * one GPU rendering the union.  The generator is the reference's Pcg (Sampler.h:11-42): 32 bits
+ * of state on one cycle of 2^32 values.  The seed is folded to 32 bits (low word xor high word)
+ * and a path starts at state pcg_hash(pixel ^ pcg_hash(sample ^ pcg_hash(seed32))): there are 2^32
+ * distinct starting points in all, paths are shifted copies of one sequence (as the reference's
+ * eight per-thread generators are), and a render of more than 2^32 samples repeats samples.  Returns after the work has finished on `stream`
  * (it polls the path queue's length while it drains). */
 int rtx_render(rtx_ctx* ctx, float* accum_dev, uint32_t spp, uint32_t sample_base, uint64_t seed,
                const float cam_offset[3], uint32_t row0, uint32_t row1, void* stream);

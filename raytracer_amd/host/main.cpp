@@ -3,7 +3,7 @@
 // render_loop (Raytracer.cpp:307-331), saving the image instead of showing a window.
 //
 //   rt_host [--obj FILE] [--width W] [--height H] [--spp N] [--passes P] [--sky]
-//           [--out PREFIX] [--checkpoint FILE] [--resume FILE] [--parse-only]
+//           [--out PREFIX] [--checkpoint FILE] [--checkpoint-every P] [--resume FILE] [--parse-only]
 //           [--pfm-to-exr IN OUT] [--dump-mesh FILE] [--gpus N]
 //
 // --gpus N renders on N GPUs of this host: the program starts N copies of itself, one rank per
@@ -16,7 +16,8 @@
 // two little-endian uint64 (triangles, materials), then 9 floats per triangle, then one uint32
 // material slot per triangle -- the arrays rtx_set_scene takes.
 //
-// --checkpoint writes the per-pixel sums and the sample count after the last pass; --resume
+// --checkpoint writes the per-pixel sums, the sample count, the seed and the scene's identity
+// after the last pass (and after every P-th pass with --checkpoint-every P); --resume
 // starts from such a file and goes on with the next sample index, so that two runs of P passes
 // end with the bits of one run of 2P.
 //
@@ -101,7 +102,7 @@ int main(int argc, char** argv) {
   bool force_comm = false;
   Ranks rk;
   std::string rendezvous;
-  uint32_t width = 800, height = 800, spp = 16, passes = 1;
+  uint32_t width = 800, height = 800, spp = 16, passes = 1, checkpoint_every = 0;
   bool sky = false, parse_only = false;
   std::string pfm_in, exr_out, resume, checkpoint, dump_mesh;
   for (int i = 1; i < argc; i++) {
@@ -122,6 +123,7 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--parse-only")) parse_only = true;
     else if (!std::strcmp(argv[i], "--resume")) resume = next("--resume");
     else if (!std::strcmp(argv[i], "--checkpoint")) checkpoint = next("--checkpoint");
+    else if (!std::strcmp(argv[i], "--checkpoint-every")) checkpoint_every = (uint32_t)std::atoi(next("--checkpoint-every"));
     else if (!std::strcmp(argv[i], "--dump-mesh")) dump_mesh = next("--dump-mesh");
     else if (!std::strcmp(argv[i], "--gpus")) gpus = std::atoi(next("--gpus"));
     else if (!std::strcmp(argv[i], "--comm")) force_comm = true;
@@ -238,6 +240,8 @@ int main(int argc, char** argv) {
                   (unsigned long long)spp * width * height, (double)spp * width * height / s);
       float total = std::chrono::duration<float>(std::chrono::high_resolution_clock::now() - t0).count();
       std::printf("Accumulated %u samples per pixel over %f seconds\n\n", img.sample_count, total);
+      if (!checkpoint.empty() && checkpoint_every && (p + 1) % checkpoint_every == 0 && p + 1 < passes)
+        save_checkpoint(img, scene, checkpoint.c_str());
     }
     rtx_stats st;
     check(rtx_get_stats(scene.ctx(), &st), "rtx_get_stats");

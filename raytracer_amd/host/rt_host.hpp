@@ -450,7 +450,37 @@ class Scene {
     s.planes = reinterpret_cast<const rtx_plane*>(planes.data());
     s.num_planes = planes.size();
     check(rtx_set_scene(ctx_, &s), "rtx_set_scene");
+    // Identity of what is being rendered, for checkpoints: FNV-1a over the configuration fields that
+    // shape the image and over every scene array.
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t n) {
+      const unsigned char* b = static_cast<const unsigned char*>(p);
+      for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 1099511628211ull;
+    };
+    mix(&cfg_.width, sizeof(cfg_.width));
+    mix(&cfg_.height, sizeof(cfg_.height));
+    mix(&cfg_.fov, sizeof(cfg_.fov));
+    mix(cfg_.cam_origin, sizeof(cfg_.cam_origin));
+    mix(&cfg_.eps, sizeof(cfg_.eps));
+    mix(&cfg_.nee_threshold, sizeof(cfg_.nee_threshold));
+    mix(&cfg_.rr_cap, sizeof(cfg_.rr_cap));
+    mix(&cfg_.sky, sizeof(cfg_.sky));
+    mix(&cfg_.max_bounces, sizeof(cfg_.max_bounces));
+    mix(&cfg_.camera, sizeof(cfg_.camera));
+    mix(&cfg_.integrator, sizeof(cfg_.integrator));
+    mix(&cfg_.focal_length, sizeof(cfg_.focal_length));
+    mix(&cfg_.lens_radius, sizeof(cfg_.lens_radius));
+    mix(&cfg_.stretch_x, sizeof(cfg_.stretch_x));
+    mix(&cfg_.stretch_y, sizeof(cfg_.stretch_y));
+    mix(tris.data(), tris.size() * sizeof(float));
+    mix(midx.data(), midx.size() * sizeof(uint32_t));
+    mix(mats.data(), mats.size() * sizeof(Material));
+    mix(spheres.data(), spheres.size() * sizeof(Sphere));
+    mix(boxes.data(), boxes.size() * sizeof(Box));
+    mix(planes.data(), planes.size() * sizeof(Plane));
+    identity_ = h;
   }
+  uint64_t identity() const { return identity_; }  // of the configuration and the committed scene
 
   rtx_ctx* ctx() const { return ctx_; }
   const rtx_config& config() const { return cfg_; }
@@ -463,6 +493,7 @@ class Scene {
   rtx_config cfg_;
   rtx_ctx* ctx_ = nullptr;
   float* accum_ = nullptr;
+  uint64_t identity_ = 0;
 };
 
 // Raytracer.cpp:47-144.  pixels holds the running mean, idx = px + py*width.
@@ -636,22 +667,55 @@ inline void render(Img& img, Scene& scene, uint32_t spp = 1, uint64_t seed = 0x5
 }
 
 // Checkpoint of an accumulation in progress -- what Img holds between passes (Img::pixels as sums,
-// Img::sample_count; Raytracer.cpp:49-59): a PFM of the per-pixel sums whose scale line carries
-// the sample count.  A render resumed from it continues with the next sample index and ends
-// with the bits of an uninterrupted one.
-inline void save_checkpoint(const Img& img, Scene& scene, const char* path) {
-  Img sums(img.width, img.height);
-  check(rtx_resolve(scene.ctx(), scene.accum(), 1, &sums.pixels[0].x, nullptr), "rtx_resolve");
-  if (!sums.savePFM(path, (float)img.sample_count)) throw Error(std::string("cannot write ") + path);
+// Img::sample_count; Raytracer.cpp:49-59) plus what makes it resumable without surprises:
+//   "RTXCKPT1" | u32 width | u32 height | u64 sample count | u64 seed | u64 scene identity |
+//   width*height*3 floats (per-pixel sums, top row first)
+// all little endian.  The file is written under another name and renamed, so a crash while
+// writing leaves the previous checkpoint intact.  A render resumed from it continues with the
+// next sample index and ends with the bits of an uninterrupted one; a checkpoint of another
+// image size, seed, configuration or scene is refused.
+inline void save_checkpoint(const Img& img, Scene& scene, const char* path, uint64_t seed = 0x5EED) {
+  std::vector<float> sums((size_t)img.width * img.height * 3);
+  check(rtx_resolve(scene.ctx(), scene.accum(), 1, sums.data(), nullptr), "rtx_resolve");
+  const std::string tmp = std::string(path) + ".tmp";
+  FILE* f = std::fopen(tmp.c_str(), "wb");
+  if (!f) throw Error(std::string("cannot write ") + tmp);
+  const uint32_t dims[2] = {img.width, img.height};
+  const uint64_t meta[3] = {img.sample_count, seed, scene.identity()};
+  bool ok = std::fwrite("RTXCKPT1", 8, 1, f) == 1 && std::fwrite(dims, sizeof(dims), 1, f) == 1 &&
+            std::fwrite(meta, sizeof(meta), 1, f) == 1 && std::fwrite(sums.data(), sizeof(float), sums.size(), f) == sums.size();
+  ok = (std::fflush(f) == 0) && ok;
+  ok = (std::fclose(f) == 0) && ok;
+  if (!ok || std::rename(tmp.c_str(), path) != 0) {
+    std::remove(tmp.c_str());
+    throw Error(std::string("cannot write ") + path);
+  }
 }
-inline void load_checkpoint(Img& img, Scene& scene, const char* path) {
-  Img sums(1, 1);
-  float count = 0;
-  if (!sums.loadPFM(path, &count)) throw Error(std::string("cannot read ") + path);
-  if (sums.width != img.width || sums.height != img.height || !(count >= 1.0f) || count != std::floor(count))
+inline void load_checkpoint(Img& img, Scene& scene, const char* path, uint64_t seed = 0x5EED) {
+  FILE* f = std::fopen(path, "rb");
+  if (!f) throw Error(std::string("cannot read ") + path);
+  char magic[8];
+  uint32_t dims[2] = {0, 0};
+  uint64_t meta[3] = {0, 0, 0};
+  std::vector<float> sums;
+  bool ok = std::fread(magic, 8, 1, f) == 1 && !std::memcmp(magic, "RTXCKPT1", 8) &&
+            std::fread(dims, sizeof(dims), 1, f) == 1 && std::fread(meta, sizeof(meta), 1, f) == 1;
+  if (ok && (dims[0] != img.width || dims[1] != img.height)) {
+    std::fclose(f);
     throw Error(std::string("checkpoint ") + path + " does not fit this image");
-  check(rtx_accum_upload(scene.ctx(), scene.accum(), &sums.pixels[0].x, nullptr), "rtx_accum_upload");
-  img.sample_count = (uint32_t)count;
+  }
+  if (ok) {
+    sums.resize((size_t)dims[0] * dims[1] * 3);
+    ok = std::fread(sums.data(), sizeof(float), sums.size(), f) == sums.size() && std::fgetc(f) == EOF;
+  }
+  std::fclose(f);
+  if (!ok) throw Error(std::string("cannot read ") + path + " (not a checkpoint, or cut short)");
+  if (meta[0] < 1 || meta[0] > 0xffffffffull) throw Error(std::string("checkpoint ") + path + " has a bad sample count");
+  if (meta[1] != seed) throw Error(std::string("checkpoint ") + path + " was rendered with another seed");
+  if (meta[2] != scene.identity())
+    throw Error(std::string("checkpoint ") + path + " was rendered from another scene or configuration");
+  check(rtx_accum_upload(scene.ctx(), scene.accum(), sums.data(), nullptr), "rtx_accum_upload");
+  img.sample_count = (uint32_t)meta[0];
   check(rtx_resolve(scene.ctx(), scene.accum(), img.sample_count, &img.pixels[0].x, nullptr), "rtx_resolve");
 }
 

@@ -114,6 +114,16 @@ def test_driver_checkpoint_and_resume_equal_one_run(rt_host, tmp_path):
     assert (tmp_path / "resumed.exr").read_bytes() == (tmp_path / "whole.exr").read_bytes()
     r = subprocess.run(common + ["--width", "64", "--resume", str(tmp_path / "half.ckpt")], capture_output=True)
     assert r.returncode == 1 and b"does not fit" in r.stderr
+    # another configuration (sky on) or a damaged file is refused as well; no half-written file is left
+    r = subprocess.run(common + ["--sky", "--resume", str(tmp_path / "half.ckpt")], capture_output=True)
+    assert r.returncode == 1 and b"another scene or configuration" in r.stderr
+    data = (tmp_path / "half.ckpt").read_bytes()
+    assert data[:8] == b"RTXCKPT1" and len(data) == 8 + 8 + 24 + 72 * 40 * 12
+    assert int.from_bytes(data[16:24], "little") == 6 and int.from_bytes(data[24:32], "little") == 0x5EED
+    (tmp_path / "cut.ckpt").write_bytes(data[:-100])
+    r = subprocess.run(common + ["--resume", str(tmp_path / "cut.ckpt")], capture_output=True)
+    assert r.returncode == 1 and b"cut short" in r.stderr
+    assert not list(tmp_path.glob("*.tmp"))
 
 
 def test_write_obj_round_trip_through_load_obj(rt_host, tmp_path):
