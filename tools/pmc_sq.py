@@ -37,7 +37,7 @@ def main():
     lines = []
     for k in sorted(sums):
         e = {c: sums[k][c] / max(launches[k][c], 1) for c in sorted(sums[k])}
-        e["launches"] = max(launches[k].values())
+        e["launches"] = min(launches[k].values())  # (a counter collected in two passes has twice the rows)
         g = lambda c: e.get(c, 0.0)
         if g("SQ_WAVES"):
             e["valu_per_wave"] = g("SQ_INSTS_VALU") / g("SQ_WAVES")
