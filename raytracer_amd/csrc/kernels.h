@@ -55,6 +55,8 @@ struct SceneDev {
   const float4* nodes;   // 4 per BVH node (bvh_build.h)
   const float4* tris;    // per triangle slot, one 64-byte record: (a.xyz, primitive id bits),
                          // (b-a, material index bits), (c-a, 0), ((b-a)x(c-a), 0)
+  const float4* tri_nrm; // per triangle slot: (normalize((b-a)x(c-a)), material index bits): what shading needs of
+                         // a hit, computed once on the host with the float operations hit_surface would use
   const float4* mat0;    // per material: (albedo.rgb, emission)
   const int* mat1;       //               surface
   // Analytic objects, in the order spheres, boxes, planes; object i of that
@@ -845,9 +847,9 @@ __device__ __forceinline__ void hit_surface(const SceneDev& sc, const Geom& g, u
     emission = m.w;
     surface = sc.sph2[i];
   } else {
-    float4 B = g.tris[g.stride * (size_t)id + 1], N = g.tris[g.stride * (size_t)id + 3];
-    n = vnormalized(mk3(N.x, N.y, N.z));
-    uint32_t mi = __float_as_uint(B.w);
+    const float4 N = sc.tri_nrm[id];  // = vnormalized(Ng), bit for bit (see rtx_set_scene)
+    n = mk3(N.x, N.y, N.z);
+    uint32_t mi = __float_as_uint(N.w);
     float4 m = sc.mat0[mi];
     albedo = mk3(m.x, m.y, m.z);
     emission = m.w;

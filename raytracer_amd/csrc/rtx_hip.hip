@@ -191,7 +191,7 @@ struct rtx_ctx {
 
   // scene
   bool have_scene = false;
-  DevBuf<float4> nodes, tris, mat0, sph0, sph1, box0, box1, pln0, pln1, light0, light1, light2, light3;
+  DevBuf<float4> nodes, tris, tri_nrm, mat0, sph0, sph1, box0, box1, pln0, pln1, light0, light1, light2, light3;
   DevBuf<int> mat1, sph2, sph3;
   rtx::SceneDev scene{};
   rtx_scene_info info{};
@@ -270,7 +270,7 @@ void free_ctx(rtx_ctx* c) {
     if (Rccl* r = rccl()) (void)r->CommDestroy(c->comm);
     c->comm = nullptr;
   }
-  c->nodes.release(); c->tris.release();
+  c->nodes.release(); c->tris.release(); c->tri_nrm.release();
   c->mat0.release(); c->mat1.release(); c->sph0.release(); c->sph1.release(); c->sph2.release(); c->sph3.release();
   c->box0.release(); c->box1.release(); c->pln0.release(); c->pln1.release();
   c->light0.release(); c->light1.release(); c->light2.release(); c->light3.release();
@@ -444,7 +444,7 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
   }
 
   const size_t nt = s->num_triangles;
-  std::vector<float4> nodes(bvh.nodes.size() / 4), tr(4 * nt);
+  std::vector<float4> nodes(bvh.nodes.size() / 4), tr(4 * nt), tn(nt);
   std::memcpy(nodes.data(), bvh.nodes.data(), bvh.nodes.size() * sizeof(float));
   for (size_t slot = 0; slot < nt; slot++) {
     uint32_t prim = bvh.order[slot];
@@ -461,7 +461,13 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
     tr[4 * slot + 1] = make_float4(bax, bay, baz, fmi);
     tr[4 * slot + 2] = make_float4(cax, cay, caz, 0.f);
     // (b-a)x(c-a) with the operations of the device's cross product (no contraction on either side)
-    tr[4 * slot + 3] = make_float4(bay * caz - baz * cay, baz * cax - bax * caz, bax * cay - bay * cax, 0.f);
+    const float nx = bay * caz - baz * cay, ny = baz * cax - bax * caz, nz = bax * cay - bay * cax;
+    tr[4 * slot + 3] = make_float4(nx, ny, nz, 0.f);
+    // The shading normal of a mesh hit, normalize(Ng) (Scene.h:181-187, Vec3.cpp:24-30): the square
+    // root of ((x*x + y*y) + z*z), then three divisions; the same IEEE operations the device would
+    // perform per hit, done once here (this file is compiled without contraction as well).
+    const float len = std::sqrt(nx * nx + ny * ny + nz * nz);
+    tn[slot] = make_float4(nx / len, ny / len, nz / len, fmi);
   }
   std::vector<float4> m0(s->num_materials);
   std::vector<int> m1(s->num_materials);
@@ -548,6 +554,7 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
   HIP_TRY(c->spill.alloc(spill_entries * (size_t)c->pool));
   HIP_TRY(c->nodes.upload(nodes));
   HIP_TRY(c->tris.upload(tr));
+  HIP_TRY(c->tri_nrm.upload(tn));
   HIP_TRY(c->mat0.upload(m0));
   HIP_TRY(c->mat1.upload(m1));
   HIP_TRY(c->sph0.upload(sp0));
@@ -564,7 +571,7 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
   HIP_TRY(c->light3.upload(l3));
 
   rtx::SceneDev& d = c->scene;
-  d.nodes = c->nodes.p; d.tris = c->tris.p;
+  d.nodes = c->nodes.p; d.tris = c->tris.p; d.tri_nrm = c->tri_nrm.p;
   d.mat0 = c->mat0.p; d.mat1 = c->mat1.p;
   d.sph0 = c->sph0.p; d.sph1 = c->sph1.p; d.sph2 = c->sph2.p; d.sph3 = c->sph3.p;
   d.box0 = c->box0.p; d.box1 = c->box1.p; d.pln0 = c->pln0.p; d.pln1 = c->pln1.p;
