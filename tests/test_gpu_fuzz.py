@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 def random_case(seed):
     rng = np.random.default_rng(seed)
-    ntri = int(rng.choice([1, 2, 5, 40, 157, 158, 400, 3000]))
+    ntri = int(rng.choice([1, 2, 5, 40, 157, 192, 193, 400, 3000]))  # 192/193: either side of the LDS/global-tree switch
     nsph = int(rng.integers(0, 4))
     sc = scenes.soup(ntri, nsph, seed=seed + 100, size=float(rng.uniform(0.05, 0.6)))
     if rng.random() < 0.5:
@@ -63,4 +63,8 @@ def test_random_case(seed, oracle, rtx_lib):
     assert ok.mean() >= 0.98, (seed, kw, float(ok.mean()))
     assert np.array_equal(np.isfinite(got).all(-1), np.isfinite(want).all(-1)) or ok.mean() >= 0.98
     if kw["camera"] != 1:   # thin lens: a last-ulp change of a lens sample can swap a short path for a chain of hundreds of bounces
-        assert abs(st.bounces - ost.bounces) <= max(0.02 * ost.bounces, 20)
+        # the same can happen at any bounce whose direction passes through sinf/cosf/powf (libm on the host, the
+        # device library on the GPU): in seed 3442 two paths of 2040 part from the oracle's (tools/fuzz_debug_sky.py),
+        # one of them stays 205 bounces longer between the spheres.  One such chain per 2000 paths is allowed.
+        chains = 300 * (1 + st.paths // 2000)
+        assert abs(st.bounces - ost.bounces) <= max(0.02 * ost.bounces, 20) + chains, (seed, kw, st.bounces, ost.bounces)
