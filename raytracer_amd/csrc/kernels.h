@@ -113,8 +113,11 @@ struct SegCounter {
   unsigned long long c[2];
   uint32_t gen_slot0, gen_count;      // k_plan's refill plan for k_generate
   unsigned long long gen_ordinal0;
-  unsigned long long pad[12];
+  uint32_t grab;                      // rays of the segment handed out so far (k_intersect_wide); k_plan clears it
+  uint32_t grab_shadow;               // the same for its light samples (k_shadow_wide)
+  unsigned long long pad[11];
 };
+static_assert(sizeof(SegCounter) == 128, "one line per segment");
 constexpr int kPathBits = 21, kShadowBits = 21;
 constexpr unsigned long long kFieldMask = (1ull << 21) - 1;
 __host__ __device__ __forceinline__ uint32_t seg_paths(unsigned long long c) { return (uint32_t)(c & kFieldMask); }
@@ -1211,6 +1214,8 @@ __global__ void k_begin(SegCounter* seg, Summary* sum, uint32_t nseg, unsigned l
     seg[s].gen_slot0 = 0;
     seg[s].gen_count = 0;
     seg[s].gen_ordinal0 = 0;
+    seg[s].grab = 0;
+    seg[s].grab_shadow = 0;
   }
   if (s == 0) {
     *pr_out = pr;  // camera and sample numbering of this call, for the kernels that recompute primary rays
@@ -1268,6 +1273,8 @@ __global__ __launch_bounds__(1024) void k_plan(SegCounter* seg, Summary* sum, in
     seg[s].gen_count = g;
     seg[s].gen_ordinal0 = next + before;
     seg[s].c[qf] = (unsigned long long)(n + g);
+    seg[s].grab = 0;
+    seg[s].grab_shadow = 0;
     if (qd >= 0) seg[s].c[qd] = 0;
   }
   // sums of g, shadow rays, light samples and drained paths; maximum of n + g
@@ -1415,42 +1422,53 @@ __global__ __launch_bounds__(BLOCK, MODE == kGlobalBvh2 ? 4 : 8) void k_intersec
   }
 }
 
-// Lanes of a wave idle at once before the wave stops to hand them new rays.
-#ifndef RTX_REFILL_LANES
-#define RTX_REFILL_LANES 8
-#endif
-constexpr uint32_t kRefillLanes = RTX_REFILL_LANES;
 constexpr uint32_t kNoRay = 0xffffffffu;
 
-// k_intersect for the wide tree in global memory.  A wave owns `rays_per_wave`
-// consecutive rays of its segment and keeps its 64 lanes supplied from them: in the
-// single-phase walk a lane whose ray has ended would only idle until the longest ray
-// of the wave ends (4 of 5 lanes on the 1 M-triangle mesh), so it stores its hit and
-// takes the next unassigned ray instead.  The next 64 unassigned rays sit prefetched
-// in registers (lane L holds ray next+L) and are handed out with lane shuffles.
+// k_intersect for the wide tree in global memory.  In the single-phase walk a lane whose ray has
+// ended would only idle until the longest ray of the wave ends (4 of 5 lanes on the 1 M-triangle
+// mesh), so a wave keeps its lanes supplied instead: the waves of a segment take its rays 64 at a
+// time from seg[s].grab until none are left, and once `refill_lanes` lanes are idle the wave
+// stores their hits and hands them the next rays of the chunk it holds.  The chunk in hand sits in
+// registers (lane L holds ray cb+L) and is handed out by lane shuffle; the base of the chunk after
+// it has already been taken, and its rays are requested as soon as it becomes the chunk in hand.
+// Against fixed runs of 256 rays per wave (which end in a tail in which the wave waits for its
+// longest ray) the 1 M-triangle mesh's launch takes 12 % less.  A wave that finds the counter at or
+// past the fill is done; the counter overshoots by up to two chunks per wave, which nothing reads.
+// Supplying lanes costs about three steps of the walk (the set-up of the new rays runs on the idle
+// lanes only, and the step after it waits for the stores and loads it issued): the threshold is
+// the host's (measured: 32 of 64 lanes for the mesh, 16 for scenes of a few thousand triangles).
+#ifndef RTX_WIDE_OCC
+#define RTX_WIDE_OCC 7
+#endif
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK, 7) void k_intersect_wide(SceneDev sc, Queue q, uint2* hits,
-                                                          const SegCounter* seg, int qi, uint32_t cap,
-                                                          uint32_t rays_per_wave, TraceParams tp) {
+__global__ __launch_bounds__(BLOCK, RTX_WIDE_OCC) void k_intersect_wide(SceneDev sc, Queue q, uint2* hits, SegCounter* seg,
+                                                          int qi, uint32_t cap, TraceParams tp, uint32_t refill_lanes) {
   constexpr int MODE = kGlobalBvh4;
   const SegBlock sb = seg_block();
   const uint32_t s = sb.s;
   const uint32_t n = seg_paths(seg[s].c[qi]);
-  constexpr uint32_t kWaves = BLOCK / 64;
-  if (sb.x * kWaves * rays_per_wave >= n) return;
+  if (sb.x * BLOCK >= n) return;  // more blocks than 64-ray chunks: nothing left for this one
   RTX_TRACE_PROLOGUE();
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t first = (sb.x * kWaves + wave) * rays_per_wave;
-  const uint32_t w_end = first + rays_per_wave < n ? first + rays_per_wave : n;
-  uint32_t next = first < n ? first : n;
   const size_t base = (size_t)s * cap;
-
+  uint32_t* const grab = &seg[s].grab;
+  // (the counter's answer stays in lane 0's register until the chunk is needed: reading it into a
+  // scalar at once would wait for the round trip)
+  auto take = [&]() -> uint32_t {
+    uint32_t v = 0;
+    if (lane == 0) v = atomicAdd(grab, 64u);
+    return v;
+  };
+  uint32_t cb = (uint32_t)__builtin_amdgcn_readfirstlane((int)take());  // chunk in hand: rays [cb + used, ce)
+  uint32_t ncb_v = take();                                              // the one after it (lane 0)
+  cb = cb < n ? cb : n;
+  uint32_t ce = cb + 64u < n ? cb + 64u : n;
+  uint32_t used = 0;
   float4 pa = make_float4(0, 0, 0, 0);
   float2 pb = make_float2(0, 0);
-  if (next + lane < w_end) {
-    pa = q.r0[base + next + lane];
-    pb = q.r1[base + next + lane];
+  if (cb + lane < ce) {
+    pa = q.r0[base + cb + lane];
+    pb = q.r1[base + cb + lane];
   }
   Walk w;
   w.o = w.d = w.inv = mk3(0, 0, 0);
@@ -1462,20 +1480,19 @@ __global__ __launch_bounds__(BLOCK, 7) void k_intersect_wide(SceneDev sc, Queue 
     const bool walking = w.cur != kTraversalDone;
     const unsigned long long wm = __ballot(walking);
     const uint32_t idle = 64u - (uint32_t)__popcll(wm);
-    if (wm == 0 || (idle >= kRefillLanes && next < w_end)) {  // wave-uniform
+    if (wm == 0 || (idle >= refill_lanes && cb + used < ce)) {  // wave-uniform
       const unsigned long long im = ~wm;
       const uint32_t rank =
           __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
-      // every lane shuffles (a shuffle reads nothing from a lane that is switched off)
-      const float ax = __shfl(pa.x, (int)rank), ay = __shfl(pa.y, (int)rank), az = __shfl(pa.z, (int)rank);
-      const float aw = __shfl(pa.w, (int)rank), bx = __shfl(pb.x, (int)rank), by = __shfl(pb.y, (int)rank);
+      const uint32_t src = used + rank;
+      const float ax = __shfl(pa.x, (int)src), ay = __shfl(pa.y, (int)src), az = __shfl(pa.z, (int)src);
+      const float aw = __shfl(pa.w, (int)src), bx = __shfl(pb.x, (int)src), by = __shfl(pb.y, (int)src);
       if (!walking) {
         if (ri != kNoRay)  // as cast_ray: the mesh hit if there is one at or before the object's distance
           hits[base + ri] = make_uint2(__float_as_uint(best.t), best.slot != kMiss ? best.slot : object_id);
-        const uint32_t j = next + rank;
         ri = kNoRay;
-        if (j < w_end) {
-          ri = j;
+        if (cb + src < ce) {
+          ri = cb + src;
           walk_begin<MODE>(sc, mk3(ax, ay, az), mk3(aw, bx, by), w);
           best.t = INFINITY;
           object_id = kMiss;
@@ -1484,13 +1501,19 @@ __global__ __launch_bounds__(BLOCK, 7) void k_intersect_wide(SceneDev sc, Queue 
           best.slot = kMiss;
         }
       }
-      next += idle;
-      next = next < w_end ? next : w_end;
-      if (next + lane < w_end) {
-        pa = q.r0[base + next + lane];
-        pb = q.r1[base + next + lane];
+      used += idle;
+      if (cb + used >= ce && cb < n) {  // chunk used up: the next one becomes the chunk in hand
+        const uint32_t ncb = (uint32_t)__builtin_amdgcn_readfirstlane((int)ncb_v);
+        cb = ncb < n ? ncb : n;
+        ce = cb + 64u < n ? cb + 64u : n;
+        used = 0;
+        if (cb < n) ncb_v = take();
+        if (cb + lane < ce) {
+          pa = q.r0[base + cb + lane];
+          pb = q.r1[base + cb + lane];
+        }
       }
-      if (__ballot(ri != kNoRay) == 0) break;
+      if (cb >= n && __ballot(ri != kNoRay) == 0) break;
     }
     if (w.cur != kTraversalDone) closest_step(geom, stk, sc.eps, w, best);
   }
@@ -1678,6 +1701,85 @@ __global__ __launch_bounds__(BLOCK, 8) void k_shadow(SceneDev sc, Queue paths, S
     float4 b = sq.q1[k];
     bool occ = occluded<MODE>(sc, geom, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), a.w, stk);
     if (!occ) add_contribution(paths, sq, k, __float_as_uint(b.w));
+  }
+}
+
+// k_shadow for the wide tree in global memory, with the lanes of a wave kept supplied as in
+// k_intersect_wide (chunks of 64 light samples taken from seg[s].grab_shadow).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK, 8) void k_shadow_wide(SceneDev sc, Queue paths, ShadowQueue sq, SegCounter* seg,
+                                                       int q_out, uint32_t cap, TraceParams tp,
+                                                       uint32_t refill_lanes) {
+  constexpr int MODE = kGlobalBvh4;
+  const SegBlock sb = seg_block();
+  const uint32_t s = sb.s;
+  const uint32_t n = seg_shadow(seg[s].c[q_out]);
+  if (sb.x * BLOCK >= n) return;
+  RTX_TRACE_PROLOGUE();
+  const uint32_t lane = threadIdx.x & 63u;
+  const size_t base = (size_t)s * cap;
+  uint32_t* const grab = &seg[s].grab_shadow;
+  auto take = [&]() -> uint32_t {
+    uint32_t v = 0;
+    if (lane == 0) v = atomicAdd(grab, 64u);
+    return v;
+  };
+  uint32_t cb = (uint32_t)__builtin_amdgcn_readfirstlane((int)take());
+  uint32_t ncb_v = take();
+  cb = cb < n ? cb : n;
+  uint32_t ce = cb + 64u < n ? cb + 64u : n;
+  uint32_t used = 0;
+  float4 pa = make_float4(0, 0, 0, 0), pb = make_float4(0, 0, 0, 0);
+  if (cb + lane < ce) {
+    pa = sq.q0[base + cb + lane];
+    pb = sq.q1[base + cb + lane];
+  }
+  Walk w;
+  w.o = w.d = w.inv = mk3(0, 0, 0);
+  w.cur = kTraversalDone;
+  w.sp = 0;
+  uint32_t ri = kNoRay, slot = 0;
+  float tfar = 0.0f;
+  bool hit = false;
+  for (;;) {
+    const bool walking = w.cur != kTraversalDone;
+    const unsigned long long wm = __ballot(walking);
+    const uint32_t idle = 64u - (uint32_t)__popcll(wm);
+    if (wm == 0 || (idle >= refill_lanes && cb + used < ce)) {  // wave-uniform
+      const unsigned long long im = ~wm;
+      const uint32_t rank =
+          __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
+      const uint32_t src = used + rank;
+      const float ax = __shfl(pa.x, (int)src), ay = __shfl(pa.y, (int)src), az = __shfl(pa.z, (int)src);
+      const float aw = __shfl(pa.w, (int)src), bx = __shfl(pb.x, (int)src), by = __shfl(pb.y, (int)src);
+      const float bz = __shfl(pb.z, (int)src), bw = __shfl(pb.w, (int)src);
+      if (!walking) {
+        if (ri != kNoRay && !hit) add_contribution(paths, sq, (uint32_t)(base + ri), slot);
+        ri = kNoRay;
+        if (cb + src < ce) {
+          ri = cb + src;
+          tfar = aw;
+          slot = __float_as_uint(bw);
+          const f3 o = mk3(ax, ay, az), d = mk3(bx, by, bz);
+          hit = analytic_any(sc, o, d, tfar);
+          if (!hit) walk_begin<MODE>(sc, o, d, w);
+        }
+      }
+      used += idle;
+      if (cb + used >= ce && cb < n) {
+        const uint32_t ncb = (uint32_t)__builtin_amdgcn_readfirstlane((int)ncb_v);
+        cb = ncb < n ? ncb : n;
+        ce = cb + 64u < n ? cb + 64u : n;
+        used = 0;
+        if (cb < n) ncb_v = take();
+        if (cb + lane < ce) {
+          pa = sq.q0[base + cb + lane];
+          pb = sq.q1[base + cb + lane];
+        }
+      }
+      if (cb >= n && __ballot(ri != kNoRay) == 0) break;
+    }
+    if (w.cur != kTraversalDone) any_step(geom, stk, sc.eps, tfar, w, hit);
   }
 }
 

@@ -51,6 +51,14 @@ int fail_nothrow(int code, const char* what, const char* detail) noexcept {
     if (e_ != hipSuccess) return fail_hip(e_, #expr);  \
   } while (0)
 
+// k_intersect_wide: waves a launch starts (flat from 28 672 to 250 000 on the 1 M-triangle mesh; with only as
+// many as the chip holds, 7 168, every segment ends at the same moment and the launch takes 25 % longer),
+// and the idle lanes at which a wave stops to supply them: 32 where the tree is larger than one L2 (mesh: 8
+// lanes 31.4 ms, 16: 30.8, 24: 29.8, 32: 29.1, 40: 30.7, 48: 33.8 per 32-spp frame), 16 below (3 000-triangle
+// soup 35.1 / 34.3 / 35.5 / 36.6 for 8 / 16 / 24 / 32; 3 200-triangle terrain 15.97 / 15.91 / 16.4 / 16.8).
+constexpr uint32_t kWideWaves = 40960;
+constexpr size_t kWideLargeTreeBytes = 4u << 20;
+
 constexpr uint32_t kDefaultPool = 1u << 24;      // 16 Mi paths in flight: 2 queues * 64 B + hits + shadow = 3.1 GB
 constexpr uint32_t kDefaultFinish = 1u << 19;    // at most this many paths left: finish them in one launch
 constexpr uint32_t kDefaultResultMiB = 8192;     // per-sample result buffer budget
@@ -217,6 +225,8 @@ struct rtx_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   DevBuf<uint4> stop4;  // per float of the image: the sample k_reduce_head stopped at
   unsigned long long overlap_min_samples = 0;  // chunks of at least this many samples split the sum
+  uint32_t wide_refill_lanes = 16;  // k_intersect_wide: idle lanes at which a wave stops to supply them
+  uint32_t shadow_refill_lanes = 32; // k_shadow_wide likewise; 0: k_shadow, one light sample per lane
 
   // multi-GPU exchange step (rtx_comm_*): this context's rank in an RCCL communicator
   ncclComm_t comm = nullptr;
@@ -594,6 +604,9 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
   d.carries_colour = emits ? 1 : 0;
   c->stack_entries = stack_entries;
   c->lds_scene_bytes = (nodes.size() / 4 + nt) * rtx::kLdsRecordStride * sizeof(float4);  // as stage_geom_lds lays it out
+  c->wide_refill_lanes = (nodes.size() + (size_t)nt * 4) * sizeof(float4) > kWideLargeTreeBytes ? 32 : 16;
+  if (const char* e = std::getenv("RTX_WIDE_REFILL_LANES")) c->wide_refill_lanes = (uint32_t)std::min(64, std::max(1, std::atoi(e)));  // (tuning hook)
+  if (const char* e = std::getenv("RTX_SHADOW_REFILL_LANES")) c->shadow_refill_lanes = (uint32_t)std::min(64, std::max(0, std::atoi(e)));  // (tuning hook)
   if (bvh.width == 4)
     c->trace_mode = rtx::kGlobalBvh4;
   else if (nt > 0 && c->lds_scene_bytes <= lds_scene_max && !std::getenv("RTX_NO_LDS_SCENE") &&  // (test hook)
@@ -638,11 +651,6 @@ static int impl_get_scene_info(rtx_ctx* c, rtx_scene_info* out) {
   } while (0)
 
 namespace {
-
-// k_intersect_wide: rays a wave owns at most (measured best of 64..2048 on the 1 M-triangle
-// mesh), and the number of waves a launch should still have.
-constexpr uint32_t kRaysPerWaveMax = 256;
-constexpr unsigned long long kWaveSlotsTarget = 16384;
 
 enum StageKind { kGen = 0, kIsect = 1, kShade = 2, kShadow = 3, kFinish = 4, kReduce = 5, kOther = 6 };
 
@@ -795,11 +803,6 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
     uint32_t gx128 = div_up(seg_max_upper, kTraceBlock);
     gx128 = std::max(1u, std::min(gx128, div_up(gx128, kTraceBatches)));
     const uint32_t gx256 = div_up(seg_max_upper, 256);
-    // Wide tree, closest hit: waves own runs of rays and refill their lanes.  Long runs keep the lanes
-    // busy, but the launch still has to cover the chip's wave slots a few times over.
-    uint32_t rpw = 64;
-    while (rpw < kRaysPerWaveMax && (unsigned long long)active_upper / (2 * rpw) >= kWaveSlotsTarget) rpw *= 2;
-    const uint32_t gxi = std::max(1u, div_up(seg_max_upper, rpw * (kTraceBlock / 64)));
     if (fused) {
       lt.begin(kShade, active_upper);
       if (fused_block == 128)
@@ -813,8 +816,11 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
     } else {
     lt.begin(kIsect, active_upper);
     if (c->trace_mode == rtx::kGlobalBvh4) {
-      rtx::k_intersect_wide<kTraceBlock><<<dim3(gxi, nseg), kTraceBlock, lds, st>>>(c->scene, qc, c->hits.p, seg, cur,
-                                                                                    cap, rpw, tp);
+      // the launch's waves spread over the segments; never more blocks than a segment has chunks of rays
+      const uint32_t per_seg = std::max(1u, div_up(kWideWaves, nseg * (kTraceBlock / 64)));
+      const uint32_t gxw = std::max(1u, std::min(per_seg, div_up(seg_max_upper, kTraceBlock)));
+      rtx::k_intersect_wide<kTraceBlock><<<dim3(gxw, nseg), kTraceBlock, lds, st>>>(c->scene, qc, c->hits.p, seg, cur,
+                                                                                    cap, tp, c->wide_refill_lanes);
     } else {
       RTX_BY_MODE(c->trace_mode, rtx::k_intersect, kTraceBlock, (dim3(gx128, nseg), kTraceBlock, lds, st),
                   (c->scene, qc, c->hits.p, seg, cur, cap, tp, prp));
@@ -832,8 +838,15 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
     }
     if (shadows) {
       lt.begin(kShadow, active_upper);
-      RTX_BY_MODE(c->trace_mode, rtx::k_shadow, kTraceBlock, (dim3(gx128, nseg), kTraceBlock, lds, st),
-                  (c->scene, qn, sq, seg, nxt, cap, tp));
+      if (c->trace_mode == rtx::kGlobalBvh4 && c->shadow_refill_lanes > 0) {
+        const uint32_t per_seg = std::max(1u, div_up(kWideWaves, nseg * (kTraceBlock / 64)));
+        const uint32_t gxw = std::max(1u, std::min(per_seg, div_up(seg_max_upper, kTraceBlock)));
+        rtx::k_shadow_wide<kTraceBlock><<<dim3(gxw, nseg), kTraceBlock, lds, st>>>(c->scene, qn, sq, seg, nxt, cap, tp,
+                                                                                   c->shadow_refill_lanes);
+      } else {
+        RTX_BY_MODE(c->trace_mode, rtx::k_shadow, kTraceBlock, (dim3(gx128, nseg), kTraceBlock, lds, st),
+                    (c->scene, qn, sq, seg, nxt, cap, tp));
+      }
       lt.end();
       launches++;
     }
