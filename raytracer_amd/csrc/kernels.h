@@ -168,7 +168,12 @@ enum TraceMode {
   kGlobalBvh2 = 0,  // two-child nodes in global memory
   kLdsBvh2 = 1,     // two-child nodes and triangles staged in LDS (small scenes)
   kGlobalBvh4 = 2,  // four-child quantised nodes in global memory (large scenes)
+  kFewTriangles = 3,  // no tree: every ray tests every triangle (meshes of up to kFewTrianglesMax)
 };
+// A mesh this small (the ground quad of the reference's sphere scenes) is tested like the analytic
+// objects: all lanes read the same records, which the compiler turns into scalar loads; no tree,
+// no stack, and no copy of the scene into LDS with the barrier behind it.
+constexpr uint32_t kFewTrianglesMax = 8;
 
 // Per-lane traversal stack: the first lds_entries entries live in LDS (one column
 // per lane, `stride` ints apart); deeper entries, which a well-built tree needs
@@ -237,10 +242,12 @@ __device__ __forceinline__ float tri_intersect(f3 a, f3 ba, f3 ca, f3 o, f3 d) {
 // Triangle `slot` against a ray.  The record carries the normal (b-a)x(c-a),
 // computed on the host with the same float operations (no contraction on either
 // side), so the lanes do not recompute it; it shares the record's 64-byte line.
+template <bool LDS_COPY = true>
 __device__ __forceinline__ float tri_test(const Geom& g, uint32_t slot, f3 o, f3 d, uint32_t& prim) {
   const float4* r = g.tris + g.stride * (size_t)slot;
   float4 A = r[0], B = r[1], C = r[2], N = r[3];
 #if RTX_FULL_RECORD_READS
+  if constexpr (LDS_COPY)
   // keeps the reads 16 bytes wide: the unused fourth components would otherwise turn them into
   // 12-byte LDS reads, which take twice the LDS cycles of a 16-byte one
   asm volatile("" ::"v"(B.w), "v"(C.w), "v"(N.w));
@@ -325,7 +332,7 @@ __device__ __forceinline__ void leaf_closest(const Geom& g, uint32_t leaf, f3 o,
   for (uint32_t k = 0; k < cnt; k++) {
     uint32_t slot = first + k;
     uint32_t prim;
-    float t = tri_test(g, slot, o, d, prim);
+    float t = tri_test<MODE != kFewTriangles>(g, slot, o, d, prim);
     if (eps < t && t < INFINITY && (t < best_t || (t == best_t && prim < best_prim))) {
       best_t = t;
       best_prim = prim;
@@ -342,7 +349,7 @@ __device__ __forceinline__ bool leaf_any(const Geom& g, uint32_t leaf, f3 o, f3 
   for (uint32_t k = 0; k < cnt; k++) {
     uint32_t slot = first + k;
     uint32_t prim;
-    float t = tri_test(g, slot, o, d, prim);
+    float t = tri_test<MODE != kFewTriangles>(g, slot, o, d, prim);
     if (eps < t && t < tfar) hit = true;
   }
   return hit;
@@ -674,6 +681,12 @@ template <int MODE>
 __device__ __forceinline__ void mesh_closest(const SceneDev& sc, const Geom& g, f3 o, f3 d, const Stack& stk,
                                              float t_limit, float& best_t, uint32_t& best_slot) {
   ClosestHit best = {t_limit, kMiss, kMiss};
+  if constexpr (MODE == kFewTriangles) {
+    if (sc.num_tris) leaf_closest<MODE>(g, sc.num_tris - 1u, o, d, sc.eps, best.t, best.prim, best.slot);  // "leaf" of all
+    best_t = best.t;
+    best_slot = best.slot;
+    return;
+  }
   Walk w;
   walk_begin<MODE>(sc, o, d, w);
   if constexpr (MODE == kGlobalBvh4) {
@@ -692,6 +705,7 @@ __device__ __forceinline__ void mesh_closest(const SceneDev& sc, const Geom& g, 
 template <int MODE>
 __device__ __forceinline__ bool mesh_any(const SceneDev& sc, const Geom& g, f3 o, f3 d, float tfar,
                                          const Stack& stk) {
+  if constexpr (MODE == kFewTriangles) return sc.num_tris && leaf_any<MODE>(g, sc.num_tris - 1u, o, d, sc.eps, tfar);
   Walk w;
   walk_begin<MODE>(sc, o, d, w);
   if constexpr (MODE == kGlobalBvh4) {

@@ -609,6 +609,8 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
   if (const char* e = std::getenv("RTX_SHADOW_REFILL_LANES")) c->shadow_refill_lanes = (uint32_t)std::min(64, std::max(0, std::atoi(e)));  // (tuning hook)
   if (bvh.width == 4)
     c->trace_mode = rtx::kGlobalBvh4;
+  else if (nt > 0 && nt <= rtx::kFewTrianglesMax && !std::getenv("RTX_NO_FEW_TRIANGLES"))  // (test hook)
+    c->trace_mode = rtx::kFewTriangles;
   else if (nt > 0 && c->lds_scene_bytes <= lds_scene_max && !std::getenv("RTX_NO_LDS_SCENE") &&  // (test hook)
            (size_t)stack_entries * kTraceBlock * sizeof(int) + c->lds_scene_bytes <= kLdsLaunchMaxBytes)
     c->trace_mode = rtx::kLdsBvh2;  // (a very deep small tree leaves the LDS to the stacks and stays in global memory)
@@ -644,6 +646,8 @@ static int impl_get_scene_info(rtx_ctx* c, rtx_scene_info* out) {
   do {                                                                       \
     if ((mode) == rtx::kLdsBvh2)                                             \
       RTX_LAUNCH(K, B, rtx::kLdsBvh2, CFG, ARGS);                            \
+    else if ((mode) == rtx::kFewTriangles)                                   \
+      RTX_LAUNCH(K, B, rtx::kFewTriangles, CFG, ARGS);                       \
     else if ((mode) == rtx::kGlobalBvh4)                                     \
       RTX_LAUNCH(K, B, rtx::kGlobalBvh4, CFG, ARGS);                         \
     else                                                                     \
@@ -698,14 +702,16 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
   rtx::ShadowQueue sq{c->sq0.p, c->sq1.p, c->sq2.p};
   const int use_depth = c->cfg.max_bounces ? 1 : 0;
   const size_t scene_lds = c->trace_mode == rtx::kLdsBvh2 ? c->lds_scene_bytes : 0;
-  const size_t lds = (size_t)c->stack_entries * kTraceBlock * sizeof(int) + scene_lds;
-  const size_t lds_fin = (size_t)c->stack_entries * kFinishBlock * sizeof(int) + scene_lds;
+  const size_t stack_lds = c->trace_mode == rtx::kFewTriangles ? 0 : (size_t)c->stack_entries * sizeof(int);  // per thread
+  const size_t lds = stack_lds * kTraceBlock + scene_lds;
+  const size_t lds_fin = stack_lds * kFinishBlock + scene_lds;
   const rtx::TraceParams tp{c->stack_entries, c->spill.p, pool};
   const bool shadows = c->scene.num_lights != 0 && c->cfg.integrator == 0;
   // One kernel for search and shading where the tree is staged in LDS.  Every block stages the
   // scene, so larger scenes get larger blocks (measured: 2 % for 128 threads below the limit,
   // 14 % for 256 at a scene of 16 KB).
-  const bool fused = c->cfg.fused_trace != 1 && c->trace_mode == rtx::kLdsBvh2;
+  const bool few = c->trace_mode == rtx::kFewTriangles;
+  const bool fused = c->cfg.fused_trace != 1 && (c->trace_mode == rtx::kLdsBvh2 || few);
   const int fused_block = c->lds_scene_bytes <= kFusedSmallSceneBytes ||
                                   (size_t)c->stack_entries * 256 * sizeof(int) + scene_lds > kLdsLaunchMaxBytes
                               ? 128
@@ -805,7 +811,10 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
     const uint32_t gx256 = div_up(seg_max_upper, 256);
     if (fused) {
       lt.begin(kShade, active_upper);
-      if (fused_block == 128)
+      if (few)
+        rtx::k_trace_shade<128, rtx::kFewTriangles><<<dim3(div_up(seg_max_upper, 128), nseg), 128, 0, st>>>(
+            c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp, sum);
+      else if (fused_block == 128)
         rtx::k_trace_shade<128, rtx::kLdsBvh2><<<dim3(div_up(seg_max_upper, 128), nseg), 128, lds_fused, st>>>(
             c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp, sum);
       else

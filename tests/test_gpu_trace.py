@@ -113,6 +113,43 @@ def test_two_child_tree_in_global_memory(oracle, rtx_lib, monkeypatch):
         assert out["global"][3].launches > out["lds"][3].launches     # no one-kernel bounce without the LDS tree
 
 
+def test_meshes_of_a_few_triangles_are_tested_without_a_tree(oracle, rtx_lib, monkeypatch):
+    """Meshes of up to eight triangles (the ground quad of the sphere scenes) are tested triangle by
+    triangle by every ray, with no tree.  RTX_NO_FEW_TRIANGLES switches that off: same hits
+    (lowest-id tie-break included: the soup's triangles overlap), same occlusion answers, same
+    image bits in one- and two-kernel bounces, and the same as the linear scan of the oracle."""
+    cfg = Config(width=120, height=80, sky=1, pool_paths=1 << 12)
+    for sc in (scenes.sphere_sky(glass=True), scenes.soup(8, 2, seed=4, size=0.9), scenes.soup(1, 0, seed=5, size=0.9)):
+        osc = oracle.OracleScene(sc, cfg)
+        rays = np.concatenate([scenes.random_rays(8000, seed=11), bounce_rays(oracle, osc, camera_rays(oracle, cfg, 48))])
+        dist = np.random.default_rng(5).uniform(0.0, 3.0, rays.shape[0]).astype(np.float32)
+        out = {}
+        for mode in ("few", "tree"):
+            if mode == "tree":
+                monkeypatch.setenv("RTX_NO_FEW_TRIANGLES", "1")
+            else:
+                monkeypatch.delenv("RTX_NO_FEW_TRIANGLES", raising=False)
+            images = []
+            for fused in (0, 1):
+                with Renderer(Config(width=120, height=80, sky=1, pool_paths=1 << 12, fused_trace=fused)) as r:
+                    r.set_scene(sc)
+                    hits = r.trace_closest(rays)
+                    occ = r.trace_occluded(rays, dist)
+                    acc = r.accum_alloc()
+                    r.render(acc, 3)
+                    images.append(r.resolve(acc, 1))
+                    st = r.stats()
+            assert np.array_equal(images[0].view(np.uint32), images[1].view(np.uint32))
+            out[mode] = (hits, occ, images[0], st)
+        monkeypatch.delenv("RTX_NO_FEW_TRIANGLES", raising=False)
+        assert_same_hits(out["few"][0], osc.trace_closest(rays, use_bvh=False))
+        assert np.array_equal(out["few"][1], osc.trace_occluded(rays, dist, use_bvh=False))
+        assert_same_hits(out["few"][0], out["tree"][0])
+        assert np.array_equal(out["few"][1], out["tree"][1])
+        assert np.array_equal(out["few"][2].view(np.uint32), out["tree"][2].view(np.uint32))
+        assert out["few"][3].bounces == out["tree"][3].bounces
+
+
 @pytest.mark.parametrize("name", ["cornell", "soup10k", "sphere_sky", "spheres_only", "ref_scene0", "ref_scene1"])
 def test_occlusion_bit_exact(name, oracle, rtx_lib):
     cfg = Config(width=800, height=800, pool_paths=1 << 16)
