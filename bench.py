@@ -271,12 +271,31 @@ def run_leg(args, workload, world, rank, local_rank, steps, warmup, profile, tor
         box = [Renderer.comm_create_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         r.comm_init(box[0], rank, world)
-    # Two sum buffers, used in turn: the RCCL reduce of one step runs on RCCL's stream while the
-    # next step renders into the other buffer.
-    accums = [torch.zeros(H * W * 3, dtype=torch.float32, device="cuda") for _ in range(2 if world > 1 else 1)]
+    # Two sum buffers, used in turn.  A step leaves its frame in flight (rtx_render_async): the next step's
+    # rounds fill the GPU while the last long paths of this one run out, and the exchange step of a frame
+    # (RCCL reduce onto rank 0) is issued once the next frame is under way.  --sync: every frame waited for
+    # (rtx_render), its reduce issued at once and overlapping the next step's render.
+    accums = [torch.zeros(H * W * 3, dtype=torch.float32, device="cuda") for _ in range(2)]
     pending = [None] * len(accums)
+    owed = [False] * len(accums)   # frames rendered and not yet exchanged
     stream = torch.cuda.current_stream().cuda_stream
     step_no = [0]
+
+    def exchange(b):
+        buf = accums[b]
+        owed[b] = False
+        if world == 1:
+            return
+        r.wait(buf)
+        if native:
+            r.comm_reduce(buf, root=0, stream=stream)  # ordered on the render stream
+        elif args.backend == "nccl":  # bands are disjoint and zero elsewhere: one sum serves tiles and sample ranges
+            pending[b] = dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM, async_op=True)
+        else:
+            host = buf.cpu()
+            dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
+            if rank == 0:
+                buf.copy_(host)
 
     def step():
         b = step_no[0] % len(accums)
@@ -285,20 +304,22 @@ def run_leg(args, workload, world, rank, local_rank, steps, warmup, profile, tor
             pending[b].wait()
             pending[b] = None
         buf = accums[b]
+        r.wait(buf)
         buf.zero_()
-        r.render(buf, spp, sample_base=base, seed=0x5EED, row0=row0, row1=row1, stream=stream)
-        if native:
-            r.comm_reduce(buf, root=0, stream=stream)  # ordered on the render stream, after this step's render
-        elif world > 1:  # bands are disjoint and zero elsewhere: one sum serves tiles and sample ranges
-            if args.backend == "nccl":
-                pending[b] = dist.reduce(buf, dst=0, op=dist.ReduceOp.SUM, async_op=True)
-            else:
-                host = buf.cpu()
-                dist.reduce(host, dst=0, op=dist.ReduceOp.SUM)
-                if rank == 0:
-                    buf.copy_(host)
+        if args.sync:
+            r.render(buf, spp, sample_base=base, seed=0x5EED, row0=row0, row1=row1, stream=stream)
+            exchange(b)
+        else:
+            r.render_async(buf, spp, sample_base=base, seed=0x5EED, row0=row0, row1=row1, stream=stream)
+            if owed[b ^ 1]:
+                exchange(b ^ 1)
+            owed[b] = True
 
     def fence():
+        for b in range(len(accums)):
+            if owed[b]:
+                exchange(b)
+        r.wait()
         for b, p in enumerate(pending):
             if p is not None:
                 p.wait()
@@ -386,6 +407,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline legs")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--no-mis", action="store_true", help="skip the second leg on the MIS Cornell scene")
+    ap.add_argument("--sync", action="store_true",
+                    help="wait for every frame (rtx_render) instead of leaving it in flight while the next one starts")
     ap.add_argument("--reduce", default="torch", choices=["torch", "native"],
                     help="who issues the sum of the per-GPU buffers: torch.distributed (RCCL through torch), or the "
                          "library's own exchange step (rtx_comm_reduce: RCCL loaded by librtx_hip.so, enqueued on "
@@ -453,8 +476,11 @@ def main():
                                    (f", {args.tiles} row bands" if args.tiles > 1 else ""),
                        "triangles": int(info.num_triangles), "spheres": int(info.num_spheres),
                        "lights": int(info.num_lights), "bvh_nodes": int(info.num_nodes),
-                       "bvh_width": int(info.bvh_width), "pool_paths": int(args.pool) or (1 << 24)},
-            "time_to_image_ms": round(elapsed / args.steps * 1e3, 3),
+                       "bvh_width": int(info.bvh_width), "pool_paths": int(args.pool) or (1 << 24),
+                       # 2: a step leaves its frame in flight and the next step starts beside its last long paths
+                       # (rtx_render_async); all frames are complete when the timed region ends
+                       "frames_in_flight": 1 if args.sync else 2},
+            "time_to_image_ms": round(elapsed / args.steps * 1e3, 3) if args.sync else None,
             "mpaths_per_s": round(paths / elapsed / 1e6, 2),
             "mshadow_rays_per_s": round(shadows / elapsed / 1e6, 2),
             "bounces_per_path": round(bounces / max(paths, 1), 3),

@@ -200,6 +200,23 @@ int rtx_get_scene_info(rtx_ctx* ctx, rtx_scene_info* out);
 int rtx_render(rtx_ctx* ctx, float* accum_dev, uint32_t spp, uint32_t sample_base, uint64_t seed,
                const float cam_offset[3], uint32_t row0, uint32_t row1, void* stream);
 
+/* rtx_render that does not wait: for loops that render frame after frame (the reference's render_loop,
+ * Raytracer.cpp:307-331, one render() per pass).  A frame ends with a few long paths (chains of
+ * hundreds of bounces inside glass) that occupy a handful of waves for about a millisecond; the next
+ * frame's work fills the GPU meanwhile.  The context keeps a second set of path queues and result
+ * slots (allocated at the first call: as much device memory again) and its own streams; frames
+ * alternate between the two sets, at most one in flight per set (a third call waits for the first
+ * frame).  Same arguments and the same sums, bit for bit, as rtx_render: frames that add to one
+ * buffer add in call order.  The work is ordered behind what `stream` holds at the time of the call,
+ * but NOT before what is enqueued on it afterwards: the sums are complete once rtx_wait, or any other
+ * call on this context that is given the buffer (rtx_resolve, rtx_comm_reduce, rtx_accum_*), or
+ * rtx_stream_synchronize / rtx_get_stats / rtx_render / rtx_set_scene has returned.  With per-launch
+ * timing switched on (rtx_set_profiling) it behaves as rtx_render. */
+int rtx_render_async(rtx_ctx* ctx, float* accum_dev, uint32_t spp, uint32_t sample_base, uint64_t seed,
+                     const float cam_offset[3], uint32_t row0, uint32_t row1, void* stream);
+/* Waits (host) for the frames of rtx_render_async that add to accum_dev; NULL = for all of them. */
+int rtx_wait(rtx_ctx* ctx, const float* accum_dev);
+
 /* Replaces the division in Img::set/Img::update (Raytracer.cpp:70-81) and the
  * hand-over of Img::pixels to the caller: rgb_out_host[i] = accum_dev[i] / total_spp,
  * width*height*3 floats.  Synchronous. */

@@ -97,6 +97,7 @@ SYMBOLS = [
     "rtx_reset_stats", "rtx_set_profiling", "rtx_accum_alloc", "rtx_accum_free", "rtx_accum_clear",
     "rtx_accum_upload", "rtx_debug_pcg", "rtx_trace_closest_noalloc",
     "rtx_comm_create_id", "rtx_comm_init", "rtx_comm_reduce", "rtx_comm_destroy", "rtx_stream_synchronize",
+    "rtx_render_async", "rtx_wait",
 ]
 
 COMM_ID_BYTES = 128
@@ -124,6 +125,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rtx_set_scene.argtypes = [vp, C.POINTER(CScene)]
     lib.rtx_get_scene_info.argtypes = [vp, C.POINTER(SceneInfo)]
     lib.rtx_render.argtypes = [vp, vp, u32, u32, u64, fp, u32, u32, vp]
+    lib.rtx_render_async.argtypes = [vp, vp, u32, u32, u64, fp, u32, u32, vp]
+    lib.rtx_wait.argtypes = [vp, vp]
     lib.rtx_resolve.argtypes = [vp, vp, u32, vp, vp]
     lib.rtx_trace_closest.argtypes = [vp, vp, sz, vp, vp, vp, vp]
     lib.rtx_trace_closest_noalloc.argtypes = [vp, vp, sz, vp, vp, vp, vp]
@@ -308,6 +311,18 @@ class Renderer:
         off = (C.c_float * 3)(*cam_offset) if cam_offset is not None else None
         self._check(self.lib.rtx_render(self._ctx, _dev_ptr(accum), spp, sample_base, seed, off,
                                         row0, row1, stream))
+
+    def render_async(self, accum, spp: int, sample_base: int = 0, seed: int = 0x5EED,
+                     cam_offset: Optional[Sequence[float]] = None, row0: int = 0, row1: int = 0,
+                     stream: int = 0):
+        """rtx_render_async: the frame is left in flight (at most two are); same sums as render()."""
+        off = (C.c_float * 3)(*cam_offset) if cam_offset is not None else None
+        self._check(self.lib.rtx_render_async(self._ctx, _dev_ptr(accum), spp, sample_base, seed, off,
+                                              row0, row1, stream))
+
+    def wait(self, accum=None):
+        """Waits for the frames of render_async that add to `accum` (None: for all)."""
+        self._check(self.lib.rtx_wait(self._ctx, _dev_ptr(accum) if accum is not None else None))
 
     def resolve(self, accum, total_spp: int, stream: int = 0) -> np.ndarray:
         out = np.empty((self.cfg.height, self.cfg.width, 3), np.float32)

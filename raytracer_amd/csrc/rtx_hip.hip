@@ -236,11 +236,28 @@ struct rtx_ctx {
   rtx_stats stats{};
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;
+
+  // Frames in flight (rtx_render_async).  A frame ends in a drain kernel that keeps a few waves busy for
+  // about a millisecond; the next frame's rounds can fill the chip meanwhile if they have queues, result
+  // slots and a stream of their own.  `twin` is that second set: a context of the same configuration whose
+  // scene fields mirror this one's (it owns no scene memory).  Frames alternate between the two sets.
+  rtx_ctx* twin = nullptr;
+  rtx_ctx* owner = nullptr;         // the context the caller holds (itself for that context): statistics go there
+  hipStream_t own = nullptr;        // the stream this set's asynchronous frames run on
+  hipEvent_t ev_in = nullptr;       // the caller's stream at the time of the call
+  hipEvent_t ev_done = nullptr;     // the frame in flight has finished (its summary is on the host)
+  hipEvent_t ev_reduced = nullptr;  // ... has been added to the sums
+  bool pending = false;             // a frame is in flight whose summary has not been absorbed
+  const float* pending_accum = nullptr;
+  uint64_t pending_iterations = 0, pending_launches = 0;
+  int next_set = 0;
 };
 
 namespace {
 
 using rtx::Queue;
+
+int wait_frames(rtx_ctx* c, const float* accum = nullptr);
 
 Queue queue_of(rtx_ctx* c, int i) {
   Queue q;
@@ -276,6 +293,17 @@ struct DeviceGuard {
 void free_ctx(rtx_ctx* c) {
   if (!c) return;
   DeviceGuard g(c->device);
+  if (c->pending && c->ev_done) (void)hipEventSynchronize(c->ev_done);
+  if (c->twin) {
+    free_ctx(c->twin);
+    c->twin = nullptr;
+  }
+  if (c->own) (void)hipStreamSynchronize(c->own);
+  if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+  if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+  if (c->ev_reduced) (void)hipEventDestroy(c->ev_reduced);
+  if (c->own) (void)hipStreamDestroy(c->own);
+
   if (c->comm) {
     if (Rccl* r = rccl()) (void)r->CommDestroy(c->comm);
     c->comm = nullptr;
@@ -414,6 +442,7 @@ static int impl_create(const rtx_config* cfg, rtx_ctx** out) {
 
 void rtx_destroy(rtx_ctx* ctx) { free_ctx(ctx); }
 
+static void mirror_scene(rtx_ctx* c);
 static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
   if (!c || !s) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_set_scene: null argument");
   if (s->num_triangles && (!s->triangles || !s->material_index || !s->materials))
@@ -427,8 +456,10 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
   for (size_t i = 0; i < s->num_triangles; i++)
     if (s->material_index[i] >= s->num_materials)
       return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_set_scene: material index out of range");
+  if (int rc = wait_frames(c)) return rc;
   DeviceGuard g(c->device);
   if (!g.ok) return fail(RTX_ERR_HIP, "rtx_set_scene: hipSetDevice failed");
+  if (c->twin) c->twin->have_scene = false;
 
   auto t_begin = std::chrono::steady_clock::now();
   // Small scenes are staged in LDS by every block and get 2-triangle leaves; with
@@ -617,6 +648,10 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
   else
     c->trace_mode = rtx::kGlobalBvh2;
   c->have_scene = true;
+  if (c->twin) {
+    mirror_scene(c);
+    if (c->spill.n != c->twin->spill.n) HIP_TRY(c->twin->spill.alloc(c->spill.n));
+  }
   c->info.num_nodes = d.num_nodes;
   c->info.num_triangles = d.num_tris;
   c->info.num_lights = d.num_lights;
@@ -693,8 +728,50 @@ uint32_t div_up(uint32_t n, uint32_t d) { return n == 0 ? 1u : (n + d - 1) / d; 
 
 // Renders samples [sample_base, sample_base+spp) of the band into the result
 // buffer and folds them into accum.  One chunk = one fill/drain of the queues.
+// Takes the summary of a finished chunk (in h_sum[0]) into the statistics.
+int absorb_summary(rtx_ctx* c, uint64_t iterations, uint64_t launches) {
+  const rtx::Summary& h = c->h_sum[0];
+  if (h.next_sample != h.total_samples)
+    return fail(RTX_ERR_HIP, "rtx_render: internal error, samples left ungenerated");
+  rtx_stats& st = (c->owner ? c->owner : c)->stats;
+  st.paths += h.stat_paths;
+  st.bounces += h.stat_bounces;
+  st.nee_samples += h.stat_nee;
+  st.shadow_rays += h.stat_shadow;
+  st.nan_paths += h.stat_nan;
+  st.truncated_paths += h.stat_truncated;
+  st.iterations += iterations;
+  st.launches += launches;
+  return RTX_OK;
+}
+
+// Waits for the frame rtx_render_async left in flight on this set, if any.
+int finish_pending(rtx_ctx* c) {
+  if (!c || !c->pending) return RTX_OK;
+  c->pending = false;
+  c->pending_accum = nullptr;
+  HIP_TRY(hipEventSynchronize(c->ev_done));
+  HIP_TRY(hipGetLastError());
+  return absorb_summary(c, c->pending_iterations, c->pending_launches);
+}
+// ... on either set (accum == nullptr), or for the frames that add to `accum`.
+int wait_frames(rtx_ctx* c, const float* accum) {
+  if (!c) return RTX_OK;
+  for (rtx_ctx* s : {c, c->twin}) {
+    if (!s || !s->pending) continue;
+    if (accum && s->pending_accum != accum) continue;
+    DeviceGuard g(s->device);
+    if (int rc = finish_pending(s)) return rc;
+  }
+  return RTX_OK;
+}
+
+// `detach`: leave the chunk in flight (its last launches enqueued, ev_done recorded behind them) instead of
+// waiting for it.  `after_reduce`: an event the chunk's additions to the sums have to wait for (the other
+// set's frame adds to the same sums first), or null.
 int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::RenderParams rp,
-                 uint32_t spp, hipStream_t st, StageTimer* timer) {
+                 uint32_t spp, hipStream_t st, StageTimer* timer, bool detach = false,
+                 hipEvent_t after_reduce = nullptr) {
   const uint32_t nseg = c->nseg, cap = c->cap, pool = c->pool;
   const unsigned long long total = (unsigned long long)rp.band_pixels * spp;
   rtx::SegCounter* seg = c->seg.p;
@@ -783,6 +860,10 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
   while (true) {
     if (left_upper == 0 && active_upper == 0) break;
     if (left_upper == 0 && active_upper <= c->finish_paths) {
+      if (after_reduce) {
+        HIP_TRY(hipStreamWaitEvent(st, after_reduce, 0));
+        after_reduce = nullptr;
+      }
       if (overlap_reduce) {
         // Most of the ordered sum runs on the side stream while the last paths run to their ends.
         rtx::k_mark_unfinished<<<dim3(div_up(seg_max_upper, 64), nseg), 64, 0, st>>>(queue_of(c, cur), seg, cur, cap,
@@ -901,6 +982,7 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
   }
   (void)finished;
   // Fold the chunk's samples into the sums, in sample order.
+  if (after_reduce) HIP_TRY(hipStreamWaitEvent(st, after_reduce, 0));
   lt.begin(kReduce, total);
   if (reduce_split) {
     HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
@@ -910,29 +992,31 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
   }
   lt.end();
   launches++;
+  if (c->ev_reduced) HIP_TRY(hipEventRecord(c->ev_reduced, st));
+  // (snapshots still on their way were enqueued before this copy: it is the last to land in h_sum[0])
   HIP_TRY(hipMemcpyAsync(&c->h_sum[0], sum, sizeof(rtx::Summary), hipMemcpyDeviceToHost, st));
+  if (detach) {
+    HIP_TRY(hipEventRecord(c->ev_done, st));
+    c->pending = true;
+    c->pending_iterations = iterations;
+    c->pending_launches = launches;
+    return RTX_OK;
+  }
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
-  const rtx::Summary& h = c->h_sum[0];
-  if (h.next_sample != h.total_samples)
-    return fail(RTX_ERR_HIP, "rtx_render: internal error, samples left ungenerated");
-  c->stats.paths += h.stat_paths;
-  c->stats.bounces += h.stat_bounces;
-  c->stats.nee_samples += h.stat_nee;
-  c->stats.shadow_rays += h.stat_shadow;
-  c->stats.nan_paths += h.stat_nan;
-  c->stats.truncated_paths += h.stat_truncated;
-  c->stats.iterations += iterations;
-  c->stats.launches += launches;
-  return RTX_OK;
+  return absorb_summary(c, iterations, launches);
 }
 
 }  // namespace
 
 extern "C" {
 
-static int impl_render(rtx_ctx* c, float* accum_dev, uint32_t spp, uint32_t sample_base, uint64_t seed,
-               const float cam_offset[3], uint32_t row0, uint32_t row1, void* stream) {
+static int ensure_twin(rtx_ctx* c);
+
+// rtx_render (async = false: on the caller's stream, returns when the frame is done) and rtx_render_async
+// (the frame goes to one of the two sets in turn, on that set's stream, and is left in flight).
+static int render_frame(rtx_ctx* c, float* accum_dev, uint32_t spp, uint32_t sample_base, uint64_t seed,
+                        const float cam_offset[3], uint32_t row0, uint32_t row1, void* stream, bool async) {
   if (!c || !accum_dev) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_render: null argument");
   if (!c->have_scene) return fail(RTX_ERR_NO_SCENE, "rtx_render: no scene set");
   if (row1 == 0) row1 = c->cfg.height;
@@ -941,7 +1025,25 @@ static int impl_render(rtx_ctx* c, float* accum_dev, uint32_t spp, uint32_t samp
   if (spp == 0) return RTX_OK;
   DeviceGuard g(c->device);
   if (!g.ok) return fail(RTX_ERR_HIP, "rtx_render: hipSetDevice failed");
+  rtx_ctx* const caller = c;
   hipStream_t st = (hipStream_t)stream;
+  hipEvent_t after_reduce = nullptr;
+  if (c->profiling) async = false;  // launches are timed one by one on the caller's stream
+  if (!async) {
+    if (int rc = wait_frames(c)) return rc;
+  } else {
+    if (int rc = ensure_twin(c)) return rc;
+    rtx_ctx* const set = caller->next_set ? caller->twin : caller;
+    rtx_ctx* const other = caller->next_set ? caller : caller->twin;
+    caller->next_set ^= 1;
+    if (int rc = finish_pending(set)) return rc;  // at most one frame per set
+    // behind what the caller has enqueued so far, and, where it adds to the sums, behind the other set's frame
+    HIP_TRY(hipEventRecord(set->ev_in, st));
+    HIP_TRY(hipStreamWaitEvent(set->own, set->ev_in, 0));
+    if (other->pending) after_reduce = other->ev_reduced;
+    st = set->own;
+    c = set;
+  }
 
   rtx::CameraDev cam{};
   cam.width = c->cfg.width;
@@ -987,9 +1089,12 @@ static int impl_render(rtx_ctx* c, float* accum_dev, uint32_t spp, uint32_t samp
   for (uint32_t done = 0; done < spp && rc == RTX_OK;) {
     const uint32_t n = (uint32_t)std::min<size_t>(chunk_spp, spp - done);
     rp.sample_base = sample_base + done;
-    rc = render_chunk(c, accum_band, cam, rp, n, st, c->profiling ? &timer : nullptr);
+    const bool last = done + n >= spp;  // (earlier chunks share the result slots with it: they are waited for)
+    rc = render_chunk(c, accum_band, cam, rp, n, st, c->profiling ? &timer : nullptr, async && last, after_reduce);
+    after_reduce = nullptr;
     done += n;
   }
+  if (async && rc == RTX_OK) c->pending_accum = accum_dev;
   if (c->profiling) {
     for (size_t i = 0; i < timer.kind.size(); i++) {
       float ms = 0.f;
@@ -1026,9 +1131,64 @@ static int impl_render(rtx_ctx* c, float* accum_dev, uint32_t spp, uint32_t samp
   return rc;
 }
 
+static int impl_render(rtx_ctx* c, float* accum_dev, uint32_t spp, uint32_t sample_base, uint64_t seed,
+                       const float cam_offset[3], uint32_t row0, uint32_t row1, void* stream) {
+  return render_frame(c, accum_dev, spp, sample_base, seed, cam_offset, row0, row1, stream, false);
+}
+static int impl_render_async(rtx_ctx* c, float* accum_dev, uint32_t spp, uint32_t sample_base, uint64_t seed,
+                             const float cam_offset[3], uint32_t row0, uint32_t row1, void* stream) {
+  return render_frame(c, accum_dev, spp, sample_base, seed, cam_offset, row0, row1, stream, true);
+}
+static int impl_wait(rtx_ctx* c, const float* accum_dev) {
+  if (!c) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_wait: null argument");
+  return wait_frames(c, accum_dev);
+}
+
+// The scene fields of the second set: the same device memory, nothing owned.
+static void mirror_scene(rtx_ctx* c) {
+  rtx_ctx* t = c->twin;
+  if (!t) return;
+  t->have_scene = c->have_scene;
+  t->scene = c->scene;
+  t->info = c->info;
+  t->stack_entries = c->stack_entries;
+  t->trace_mode = c->trace_mode;
+  t->lds_scene_bytes = c->lds_scene_bytes;
+  t->wide_refill_lanes = c->wide_refill_lanes;
+  t->shadow_refill_lanes = c->shadow_refill_lanes;
+}
+static int ensure_twin(rtx_ctx* c) {
+  auto events = [](rtx_ctx* s) -> int {
+    if (s->own) return RTX_OK;
+    HIP_TRY(hipStreamCreateWithFlags(&s->own, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&s->ev_reduced, hipEventDisableTiming));
+    return RTX_OK;
+  };
+  if (int rc = events(c)) return rc;
+  c->owner = c;
+  if (!c->twin) {
+    rtx_config cfg = c->cfg;
+    cfg.device = c->device;
+    rtx_ctx* t = nullptr;
+    if (int rc = impl_create(&cfg, &t)) return rc;
+    t->owner = c;
+    t->finish_paths = c->finish_paths;
+    t->overlap_min_samples = c->overlap_min_samples;
+    c->twin = t;
+    if (int rc = events(t)) return rc;
+  }
+  mirror_scene(c);
+  // the stacks' spill columns are per launched thread: the second set needs its own
+  if (c->spill.n != c->twin->spill.n) HIP_TRY(c->twin->spill.alloc(c->spill.n));
+  return RTX_OK;
+}
+
 static int impl_resolve(rtx_ctx* c, const float* accum_dev, uint32_t total_spp, float* rgb_out_host, void* stream) {
   if (!c || !accum_dev || !rgb_out_host) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_resolve: null argument");
   if (total_spp == 0) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_resolve: total_spp is 0");
+  if (int rc = wait_frames(c, accum_dev)) return rc;
   DeviceGuard g(c->device);
   if (!g.ok) return fail(RTX_ERR_HIP, "rtx_resolve: hipSetDevice failed");
   hipStream_t st = (hipStream_t)stream;
@@ -1043,6 +1203,7 @@ static int impl_trace_closest(rtx_ctx* c, const float* rays_host, size_t n, uint
                       float* t_out, float* normal_out) {
   if (!c || (n && (!rays_host || !kind_out || !prim_out || !t_out)))
     return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_trace_closest: null argument");
+  if (int rc = wait_frames(c)) return rc;  // (the traversal stacks' spill columns are shared with the frames)
   if (!c->have_scene) return fail(RTX_ERR_NO_SCENE, "rtx_trace_closest: no scene set");
   if (n == 0) return RTX_OK;
   if (n > 0x7fffffffu) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_trace_closest: too many rays");
@@ -1093,6 +1254,7 @@ static int impl_trace_closest_noalloc(rtx_ctx* c, const float* rays_host, size_t
                                       uint32_t* prim_out, float* t_out, float* normal_out) {
   if (!c || (n && (!rays_host || !kind_out || !prim_out || !t_out)))
     return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_trace_closest_noalloc: null argument");
+  if (int rc = wait_frames(c)) return rc;  // (the traversal stacks' spill columns are shared with the frames)
   if (!c->have_scene) return fail(RTX_ERR_NO_SCENE, "rtx_trace_closest_noalloc: no scene set");
   if (n == 0) return RTX_OK;
   if (n > kNoAllocMaxRays)
@@ -1133,6 +1295,7 @@ static int impl_trace_occluded(rtx_ctx* c, const float* rays_host, const float* 
                        uint8_t* occluded_out) {
   if (!c || (n && (!rays_host || !distance_host || !occluded_out)))
     return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_trace_occluded: null argument");
+  if (int rc = wait_frames(c)) return rc;  // (the traversal stacks' spill columns are shared with the frames)
   if (!c->have_scene) return fail(RTX_ERR_NO_SCENE, "rtx_trace_occluded: no scene set");
   if (n == 0) return RTX_OK;
   if (n > 0x7fffffffu) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_trace_occluded: too many rays");
@@ -1199,6 +1362,7 @@ static int impl_comm_reduce(rtx_ctx* c, float* accum_dev, int root, void* stream
   if (!c || !accum_dev) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_comm_reduce: null argument");
   if (!c->comm) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_comm_reduce: no communicator (rtx_comm_init)");
   if (root < 0 || root >= c->comm_world) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_comm_reduce: bad root");
+  if (int rc = wait_frames(c, accum_dev)) return rc;
   DeviceGuard g(c->device);
   if (!g.ok) return fail(RTX_ERR_HIP, "rtx_comm_reduce: hipSetDevice failed");
   const size_t n = (size_t)c->cfg.width * c->cfg.height * 3;
@@ -1219,6 +1383,7 @@ static int impl_comm_destroy(rtx_ctx* c) {
 }
 static int impl_stream_sync(rtx_ctx* c, void* stream) {
   if (!c) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_stream_synchronize: null argument");
+  if (int rc = wait_frames(c)) return rc;
   DeviceGuard g(c->device);
   if (!g.ok) return fail(RTX_ERR_HIP, "rtx_stream_synchronize: hipSetDevice failed");
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
@@ -1258,16 +1423,19 @@ static int impl_debug_pcg(rtx_ctx* c, uint32_t seed, uint32_t n, uint32_t* rand_
 
 static int impl_get_stats(rtx_ctx* c, rtx_stats* out) {
   if (!c || !out) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_get_stats: null argument");
+  if (int rc = wait_frames(c)) return rc;
   *out = c->stats;
   return RTX_OK;
 }
 static int impl_reset_stats(rtx_ctx* c) {
   if (!c) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_reset_stats: null argument");
+  if (int rc = wait_frames(c)) return rc;
   c->stats = rtx_stats{};
   return RTX_OK;
 }
 static int impl_set_profiling(rtx_ctx* c, int on) {
   if (!c) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_set_profiling: null argument");
+  if (int rc = wait_frames(c)) return rc;
   c->profiling = on != 0;
   return RTX_OK;
 }
@@ -1283,12 +1451,14 @@ static int impl_accum_alloc(rtx_ctx* c, float** out) {
 }
 static int impl_accum_free(rtx_ctx* c, float* p) {
   if (!c) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_accum_free: null argument");
+  if (int rc = wait_frames(c, p)) return rc;
   DeviceGuard g(c->device);
   if (p) HIP_TRY(hipFree(p));
   return RTX_OK;
 }
 static int impl_accum_clear(rtx_ctx* c, float* p, void* stream) {
   if (!c || !p) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_accum_clear: null argument");
+  if (int rc = wait_frames(c, p)) return rc;
   DeviceGuard g(c->device);
   size_t bytes = (size_t)c->cfg.width * c->cfg.height * 3 * sizeof(float);
   HIP_TRY(hipMemsetAsync(p, 0, bytes, (hipStream_t)stream));
@@ -1297,6 +1467,7 @@ static int impl_accum_clear(rtx_ctx* c, float* p, void* stream) {
 
 static int impl_accum_upload(rtx_ctx* c, float* p, const float* sums_host, void* stream) {
   if (!c || !p || !sums_host) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_accum_upload: null argument");
+  if (int rc = wait_frames(c, p)) return rc;
   DeviceGuard g(c->device);
   if (!g.ok) return fail(RTX_ERR_HIP, "rtx_accum_upload: hipSetDevice failed");
   size_t bytes = (size_t)c->cfg.width * c->cfg.height * 3 * sizeof(float);
@@ -1337,6 +1508,12 @@ int rtx_get_scene_info(rtx_ctx* c, rtx_scene_info* out) {
 }
 int rtx_render(rtx_ctx* c, float* accum_dev, uint32_t spp, uint32_t sample_base, uint64_t seed, const float cam_offset[3], uint32_t row0, uint32_t row1, void* stream) {
   return guarded("rtx_render", [&] { return impl_render(c, accum_dev, spp, sample_base, seed, cam_offset, row0, row1, stream); });
+}
+int rtx_render_async(rtx_ctx* c, float* accum_dev, uint32_t spp, uint32_t sample_base, uint64_t seed, const float cam_offset[3], uint32_t row0, uint32_t row1, void* stream) {
+  return guarded("rtx_render_async", [&] { return impl_render_async(c, accum_dev, spp, sample_base, seed, cam_offset, row0, row1, stream); });
+}
+int rtx_wait(rtx_ctx* c, const float* accum_dev) {
+  return guarded("rtx_wait", [&] { return impl_wait(c, accum_dev); });
 }
 int rtx_resolve(rtx_ctx* c, const float* accum_dev, uint32_t total_spp, float* rgb_out_host, void* stream) {
   return guarded("rtx_resolve", [&] { return impl_resolve(c, accum_dev, total_spp, rgb_out_host, stream); });

@@ -4,7 +4,11 @@
 //
 //   rt_host [--obj FILE] [--width W] [--height H] [--spp N] [--passes P] [--sky]
 //           [--out PREFIX] [--checkpoint FILE] [--checkpoint-every P] [--resume FILE] [--parse-only]
-//           [--pfm-to-exr IN OUT] [--dump-mesh FILE] [--gpus N]
+//           [--pfm-to-exr IN OUT] [--dump-mesh FILE] [--gpus N] [--in-flight]
+//
+// --in-flight leaves every pass in flight (rtx_render_async, two at a time) instead of waiting for
+// it and refreshing the image: the next pass's work fills the GPU while the last long paths of this
+// one run out.  The image is read back for checkpoints and at the end; same bits.
 //
 // --gpus N renders on N GPUs of this host: the program starts N copies of itself, one rank per
 // GPU (before it has touched a GPU itself), every rank renders its share of each pass's samples,
@@ -103,7 +107,7 @@ int main(int argc, char** argv) {
   Ranks rk;
   std::string rendezvous;
   uint32_t width = 800, height = 800, spp = 16, passes = 1, checkpoint_every = 0;
-  bool sky = false, parse_only = false;
+  bool sky = false, parse_only = false, in_flight = false;
   std::string pfm_in, exr_out, resume, checkpoint, dump_mesh;
   for (int i = 1; i < argc; i++) {
     auto next = [&](const char* name) -> const char* {
@@ -123,6 +127,7 @@ int main(int argc, char** argv) {
     else if (!std::strcmp(argv[i], "--parse-only")) parse_only = true;
     else if (!std::strcmp(argv[i], "--resume")) resume = next("--resume");
     else if (!std::strcmp(argv[i], "--checkpoint")) checkpoint = next("--checkpoint");
+    else if (!std::strcmp(argv[i], "--in-flight")) in_flight = true;
     else if (!std::strcmp(argv[i], "--checkpoint-every")) checkpoint_every = (uint32_t)std::atoi(next("--checkpoint-every"));
     else if (!std::strcmp(argv[i], "--dump-mesh")) dump_mesh = next("--dump-mesh");
     else if (!std::strcmp(argv[i], "--gpus")) gpus = std::atoi(next("--gpus"));
@@ -231,6 +236,8 @@ int main(int argc, char** argv) {
       auto tp = std::chrono::high_resolution_clock::now();
       if (ranks)
         render_ranks(img, scene, rk, spp);
+      else if (in_flight)
+        render_in_flight(img, scene, spp);
       else
         render(img, scene, spp);
       if (!root) continue;
@@ -240,9 +247,12 @@ int main(int argc, char** argv) {
                   (unsigned long long)spp * width * height, (double)spp * width * height / s);
       float total = std::chrono::duration<float>(std::chrono::high_resolution_clock::now() - t0).count();
       std::printf("Accumulated %u samples per pixel over %f seconds\n\n", img.sample_count, total);
-      if (!checkpoint.empty() && checkpoint_every && (p + 1) % checkpoint_every == 0 && p + 1 < passes)
+      if (!checkpoint.empty() && checkpoint_every && (p + 1) % checkpoint_every == 0 && p + 1 < passes) {
+        if (in_flight) refresh(img, scene);
         save_checkpoint(img, scene, checkpoint.c_str());
+      }
     }
+    if (in_flight && !ranks) refresh(img, scene);
     rtx_stats st;
     check(rtx_get_stats(scene.ctx(), &st), "rtx_get_stats");
     if (!root) {

@@ -666,6 +666,20 @@ inline void render(Img& img, Scene& scene, uint32_t spp = 1, uint64_t seed = 0x5
   check(rtx_resolve(scene.ctx(), scene.accum(), img.sample_count, &img.pixels[0].x, nullptr), "rtx_resolve");
 }
 
+// The same without waiting for the pass (rtx_render_async: two passes in flight, the second one's
+// work fills the GPU while the last long paths of the first run out); img.pixels is not refreshed
+// until refresh() is called.  Same sums as render().
+inline void render_in_flight(Img& img, Scene& scene, uint32_t spp = 1, uint64_t seed = 0x5EED, Vec3 pos = Vec3()) {
+  const float off[3] = {pos.x, pos.y, pos.z};
+  check(rtx_render_async(scene.ctx(), scene.accum(), spp, img.sample_count, seed, off, 0, 0, nullptr),
+        "rtx_render_async");
+  img.sample_count += spp;
+}
+inline void refresh(Img& img, Scene& scene) {  // waits for the passes in flight
+  if (img.sample_count == 0) return;
+  check(rtx_resolve(scene.ctx(), scene.accum(), img.sample_count, &img.pixels[0].x, nullptr), "rtx_resolve");
+}
+
 // Checkpoint of an accumulation in progress -- what Img holds between passes (Img::pixels as sums,
 // Img::sample_count; Raytracer.cpp:49-59) plus what makes it resumable without surprises:
 //   "RTXCKPT1" | u32 width | u32 height | u64 sample count | u64 seed | u64 scene identity |

@@ -126,6 +126,19 @@ def test_driver_checkpoint_and_resume_equal_one_run(rt_host, tmp_path):
     assert not list(tmp_path.glob("*.tmp"))
 
 
+@pytest.mark.gpu
+def test_driver_passes_in_flight_write_the_same_files(rt_host, tmp_path):
+    """--in-flight (rtx_render_async, two passes at a time, image read back at checkpoints and at the
+    end) writes the files of the pass-by-pass run, byte for byte, checkpoint included."""
+    common = [rt_host, "--width", "72", "--height", "40", "--spp", "3", "--passes", "5", "--checkpoint-every", "2"]
+    subprocess.check_call(common + ["--out", str(tmp_path / "a"), "--checkpoint", str(tmp_path / "a.ckpt")],
+                          stdout=subprocess.DEVNULL)
+    subprocess.check_call(common + ["--in-flight", "--out", str(tmp_path / "b"), "--checkpoint", str(tmp_path / "b.ckpt")],
+                          stdout=subprocess.DEVNULL)
+    for ext in (".pfm", ".exr", ".ppm", ".ckpt"):
+        assert (tmp_path / ("a" + ext)).read_bytes() == (tmp_path / ("b" + ext)).read_bytes(), ext
+
+
 def test_write_obj_round_trip_through_load_obj(rt_host, tmp_path):
     """scenes.through_obj: a mesh written as OBJ + MTL and parsed by the host layer's load_obj comes
     back bit for bit (coordinates, triangle order, vertex order, material slots)."""
