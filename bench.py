@@ -271,14 +271,21 @@ def run_leg(args, workload, world, rank, local_rank, steps, warmup, profile, tor
         box = [Renderer.comm_create_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
         r.comm_init(box[0], rank, world)
-    # Two sum buffers, used in turn.  A step leaves its frame in flight (rtx_render_async): the next step's
+    # A ring of four sum buffers.  A step leaves its frame in flight (rtx_render_async): the next step's
     # rounds fill the GPU while the last long paths of this one run out, and the exchange step of a frame
-    # (RCCL reduce onto rank 0) is issued once the next frame is under way.  --sync: every frame waited for
-    # (rtx_render), its reduce issued at once and overlapping the next step's render.
-    accums = [torch.zeros(H * W * 3, dtype=torch.float32, device="cuda") for _ in range(2)]
-    pending = [None] * len(accums)
-    owed = [False] * len(accums)   # frames rendered and not yet exchanged
-    stream = torch.cuda.current_stream().cuda_stream
+    # (RCCL reduce onto rank 0) is issued once the next frame is under way.  A buffer is cleared two steps
+    # before its turn, on a stream of its own: a clear issued between two frames runs beside the ordered sum
+    # of the frame that has just ended, which has the memory system to itself, and a frame that had to wait
+    # for it would start a third of a millisecond late.  --sync: every frame waited for (rtx_render), its
+    # reduce issued at once and overlapping the next step's render.
+    NB = 4
+    accums = [torch.zeros(H * W * 3, dtype=torch.float32, device="cuda") for _ in range(NB)]
+    pending = [None] * NB
+    owed = [False] * NB            # frames rendered and not yet exchanged
+    cleared = [None] * NB          # event behind the clear of a buffer that is ready for its next frame
+    main = torch.cuda.current_stream()
+    clear_stream = torch.cuda.Stream()
+    stream = main.cuda_stream
     step_no = [0]
 
     def exchange(b):
@@ -297,26 +304,40 @@ def run_leg(args, workload, world, rank, local_rank, steps, warmup, profile, tor
             if rank == 0:
                 buf.copy_(host)
 
+    def clear(b):
+        """Clears buffer b once its last frame and that frame's exchange are done."""
+        if owed[b]:
+            exchange(b)
+        r.wait(accums[b])
+        clear_stream.wait_stream(main)          # the native reduce and the gloo copy run on the main stream
+        with torch.cuda.stream(clear_stream):
+            if pending[b] is not None:          # (a stream-level wait for RCCL's stream)
+                pending[b].wait()
+                pending[b] = None
+            accums[b].zero_()
+            cleared[b] = clear_stream.record_event()
+
     def step():
-        b = step_no[0] % len(accums)
+        k = step_no[0]
+        b = k % NB
         step_no[0] += 1
-        if pending[b] is not None:  # the reduce that last read this buffer (two steps ago)
-            pending[b].wait()
-            pending[b] = None
+        if cleared[b] is None:
+            clear(b)
+        cleared[b].synchronize()   # (long done; a wait enqueued on the stream would be one more thing in its queue)
+        cleared[b] = None
         buf = accums[b]
-        r.wait(buf)
-        buf.zero_()
         if args.sync:
             r.render(buf, spp, sample_base=base, seed=0x5EED, row0=row0, row1=row1, stream=stream)
             exchange(b)
         else:
             r.render_async(buf, spp, sample_base=base, seed=0x5EED, row0=row0, row1=row1, stream=stream)
-            if owed[b ^ 1]:
-                exchange(b ^ 1)
             owed[b] = True
+            if owed[(b - 1) % NB]:
+                exchange((b - 1) % NB)
+        clear((b + 2) % NB)
 
     def fence():
-        for b in range(len(accums)):
+        for b in range(NB):
             if owed[b]:
                 exchange(b)
         r.wait()

@@ -797,7 +797,10 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
   const uint32_t nfloats = rp.band_pixels * 3;
   // (not while launches are being timed one by one: the two halves of the sum would not add up to a stage)
   // (and not for small chunks: the extra launches and events cost more than the sum)
-  const bool overlap_reduce = kOverlapReduce && !timer && (nfloats & 3u) == 0 && total >= c->overlap_min_samples;
+  // (nor for a frame left in flight: the next frame's rounds run beside its drain kernel and its sum alike, and a
+  // third stream would have to share one of the process's four hardware queues with something)
+  const bool overlap_reduce =
+      kOverlapReduce && !timer && !detach && (nfloats & 3u) == 0 && total >= c->overlap_min_samples;
   bool reduce_split = false;
   const uint32_t plan_threads = (nseg + 63u) / 64u * 64u;  // k_plan: one thread per segment, whole waves
   LaunchTimer lt(c, st, timer);
@@ -869,10 +872,7 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
         rtx::k_mark_unfinished<<<dim3(div_up(seg_max_upper, 64), nseg), 64, 0, st>>>(queue_of(c, cur), seg, cur, cap,
                                                                                    c->res.p, prp);
         HIP_TRY(hipEventRecord(c->ev_fork, st));
-        HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-        rtx::k_reduce_head<<<div_up(nfloats / 4, 256), 256, 0, c->side>>>(c->res.p, accum_band, c->stop4.p, nfloats, spp);
-        HIP_TRY(hipEventRecord(c->ev_join, c->side));
-        launches += 2;
+        launches++;
         reduce_split = true;
       }
       lt.begin(kFinish, active_upper);
@@ -881,6 +881,14 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
                   (c->scene, queue_of(c, cur), seg, cur, cap, c->res.p, sum, tp, prp));
       lt.end();
       launches++;
+      if (reduce_split) {
+        // (enqueued behind the drain kernel: the other way round the sum's twelve thousand blocks can hold
+        // the drain kernel's few back until they are all out, and the two run one after the other)
+        HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+        rtx::k_reduce_head<<<div_up(nfloats / 4, 256), 256, 0, c->side>>>(c->res.p, accum_band, c->stop4.p, nfloats, spp);
+        HIP_TRY(hipEventRecord(c->ev_join, c->side));
+        launches++;
+      }
       finished = true;
       break;
     }
@@ -1038,8 +1046,15 @@ static int render_frame(rtx_ctx* c, float* accum_dev, uint32_t spp, uint32_t sam
     caller->next_set ^= 1;
     if (int rc = finish_pending(set)) return rc;  // at most one frame per set
     // behind what the caller has enqueued so far, and, where it adds to the sums, behind the other set's frame
-    HIP_TRY(hipEventRecord(set->ev_in, st));
-    HIP_TRY(hipStreamWaitEvent(set->own, set->ev_in, 0));
+    // (an idle stream needs no marker: a marker would queue up behind whatever shares the caller's stream's
+    // hardware queue, four per process here, and the frame with it)
+    const hipError_t busy = hipStreamQuery(st);
+    if (busy == hipErrorNotReady) {
+      HIP_TRY(hipEventRecord(set->ev_in, st));
+      HIP_TRY(hipStreamWaitEvent(set->own, set->ev_in, 0));
+    } else if (busy != hipSuccess) {
+      return fail_hip(busy, "hipStreamQuery");
+    }
     if (other->pending) after_reduce = other->ev_reduced;
     st = set->own;
     c = set;
