@@ -312,11 +312,11 @@ __device__ __forceinline__ float plane_intersect(f3 pt, f3 n, f3 o, f3 d) {
 // origin.  The comparison's slack covers the relative errors (fma rounding and the
 // reciprocal's ulp).  The inverse is finite (clamped), so no term is NaN.
 __device__ __forceinline__ bool slab(float lox, float hix, float loy, float hiy, float loz, float hiz,
-                                     f3 inv, f3 add_lo, f3 add_hi, float tmax, float& tnear) {
+                                     f3 inv, f3 add_lo, f3 add_hi, float tmin, float tmax, float& tnear) {
   float ax = __builtin_fmaf(lox, inv.x, add_lo.x), bx = __builtin_fmaf(hix, inv.x, add_hi.x);
   float ay = __builtin_fmaf(loy, inv.y, add_lo.y), by = __builtin_fmaf(hiy, inv.y, add_hi.y);
   float az = __builtin_fmaf(loz, inv.z, add_lo.z), bz = __builtin_fmaf(hiz, inv.z, add_hi.z);
-  float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+  float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
   float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
   tnear = tn;
   return tn <= tf * 1.000001f;
@@ -367,7 +367,7 @@ struct Node4Test {
 };
 __device__ __forceinline__ float ubyte_f(uint32_t w, int i) { return (float)((w >> (8 * i)) & 0xffu); }
 __device__ __forceinline__ Node4Test test_node4(float4 q0, float4 q1f, float4 q2f, float4 q3f, f3 o, f3 inv,
-                                                float tmax, int4& refs) {
+                                                float tmin, float tmax, int4& refs) {
   const uint32_t ew = __float_as_uint(q0.w);
   const float ax = __uint_as_float((ew & 0xffu) << 23) * inv.x;
   const float ay = __uint_as_float(((ew >> 8) & 0xffu) << 23) * inv.y;
@@ -386,7 +386,7 @@ __device__ __forceinline__ Node4Test test_node4(float4 q0, float4 q1f, float4 q2
     float tnx = __builtin_fmaf(ubyte_f(nx, i), ax, bx), tfx = __builtin_fmaf(ubyte_f(fx, i), ax, bx);
     float tny = __builtin_fmaf(ubyte_f(ny, i), ay, by), tfy = __builtin_fmaf(ubyte_f(fy, i), ay, by);
     float tnz = __builtin_fmaf(ubyte_f(nz, i), az, bz), tfz = __builtin_fmaf(ubyte_f(fz, i), az, bz);
-    float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, 0.0f));
+    float tn = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, tmin));
     float tf = fminf(fminf(tfx, tfy), fminf(tfz, tmax));
     out.tn[i] = tn;
     out.hit[i] = tn <= tf * 1.0000004f && r[i] != kTraversalDone;
@@ -425,6 +425,7 @@ __device__ __forceinline__ void order2(float& ta, int& ra, float& tb, int& rb) {
 struct Walk {
   f3 o, d, inv;
   f3 add_lo, add_hi;  // two-child nodes only: the slab test's addends, see slab()
+  float tmin;         // boxes the ray has left before this distance are skipped, see walk_begin
   int cur, sp;
 };
 template <int MODE>
@@ -442,6 +443,12 @@ __device__ __forceinline__ void walk_begin(const SceneDev& sc, f3 o, f3 d, Walk&
     w.add_lo = mk3(nb.x - e.x, nb.y - e.y, nb.z - e.z);
     w.add_hi = mk3(nb.x + e.x, nb.y + e.y, nb.z + e.z);
   }
+  // A hit needs eps < t (Obj.h:184-195, Scene.h:216-217), so a box the ray leaves before eps holds none: above
+  // all the box of the surface the ray starts on, whose two triangles every bounce and every light sample would
+  // otherwise test for nothing.  Half of eps leaves room for the noise of a computed t: the boxes are padded by
+  // 1e-5 of their diagonal, fifty times the rounding of n.(o-a) for a vertex that far away, so a triangle whose
+  // computed t passes eps has its true crossing, and with it its box, beyond eps/2.
+  w.tmin = 0.5f * sc.eps;
   w.cur = sc.num_nodes == 0 ? (int)kTraversalDone : 0;
   w.sp = 0;
 }
@@ -459,8 +466,8 @@ __device__ __forceinline__ void closest_node_step(const Geom& g, const Stack& st
   const float4* nd = g.nodes + g.stride * (size_t)w.cur;
   float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
   float tn0, tn1;
-  bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, w.inv, w.add_lo, w.add_hi, best.t, tn0);
-  bool h1 = slab(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, w.inv, w.add_lo, w.add_hi, best.t, tn1);
+  bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, w.inv, w.add_lo, w.add_hi, w.tmin, best.t, tn0);
+  bool h1 = slab(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, w.inv, w.add_lo, w.add_hi, w.tmin, best.t, tn1);
   int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
   if (h0 && h1) {
     bool swap = tn1 < tn0;
@@ -481,7 +488,7 @@ __device__ __forceinline__ void closest_nodes(const Geom& g, const Stack& stk, W
     while (w.cur >= 0) {
       int4 refs;
       const float4* nd = g.nodes + g.stride * (size_t)w.cur;
-      Node4Test nt = test_node4(nd[0], nd[1], nd[2], nd[3], w.o, w.inv, best.t, refs);
+      Node4Test nt = test_node4(nd[0], nd[1], nd[2], nd[3], w.o, w.inv, w.tmin, best.t, refs);
       float t0 = nt.hit[0] ? nt.tn[0] : INFINITY, t1 = nt.hit[1] ? nt.tn[1] : INFINITY;
       float t2 = nt.hit[2] ? nt.tn[2] : INFINITY, t3 = nt.hit[3] ? nt.tn[3] : INFINITY;
       int r0 = refs.x, r1 = refs.y, r2 = refs.z, r3 = refs.w;
@@ -521,7 +528,7 @@ __device__ __forceinline__ void any_nodes(const Geom& g, const Stack& stk, Walk&
     while (w.cur >= 0) {
       int4 refs;
       const float4* nd = g.nodes + g.stride * (size_t)w.cur;
-      Node4Test nt = test_node4(nd[0], nd[1], nd[2], nd[3], w.o, w.inv, tfar, refs);
+      Node4Test nt = test_node4(nd[0], nd[1], nd[2], nd[3], w.o, w.inv, w.tmin, tfar, refs);
       int next = kTraversalDone;
       if (nt.hit[3]) next = refs.w;
       if (nt.hit[2]) {
@@ -543,8 +550,8 @@ __device__ __forceinline__ void any_nodes(const Geom& g, const Stack& stk, Walk&
       const float4* nd = g.nodes + g.stride * (size_t)w.cur;
       float4 q0 = nd[0], q1 = nd[1], q2 = nd[2], q3 = nd[3];
       float tn0, tn1;
-      bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, w.inv, w.add_lo, w.add_hi, tfar, tn0);
-      bool h1 = slab(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, w.inv, w.add_lo, w.add_hi, tfar, tn1);
+      bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q2.x, q2.y, w.inv, w.add_lo, w.add_hi, w.tmin, tfar, tn0);
+      bool h1 = slab(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w, w.inv, w.add_lo, w.add_hi, w.tmin, tfar, tn1);
       int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
       if (h0 && h1) {
         stk.push(w.sp, c1);
@@ -599,7 +606,7 @@ __device__ __forceinline__ void closest_step(const Geom& g, const Stack& stk, fl
     const float4 q0 = as_float4(rec[0]), q1 = as_float4(rec[1]), q2 = as_float4(rec[2]), q3 = as_float4(rec[3]);
     if (w.cur >= 0) {
       int4 refs;
-      Node4Test nt = test_node4(q0, q1, q2, q3, w.o, w.inv, best.t, refs);
+      Node4Test nt = test_node4(q0, q1, q2, q3, w.o, w.inv, w.tmin, best.t, refs);
       float t0 = nt.hit[0] ? nt.tn[0] : INFINITY, t1 = nt.hit[1] ? nt.tn[1] : INFINITY;
       float t2 = nt.hit[2] ? nt.tn[2] : INFINITY, t3 = nt.hit[3] ? nt.tn[3] : INFINITY;
       int r0 = refs.x, r1 = refs.y, r2 = refs.z, r3 = refs.w;
@@ -641,7 +648,7 @@ __device__ __forceinline__ void any_step(const Geom& g, const Stack& stk, float 
     const float4 q0 = as_float4(rec[0]), q1 = as_float4(rec[1]), q2 = as_float4(rec[2]), q3 = as_float4(rec[3]);
     if (w.cur >= 0) {
       int4 refs;
-      Node4Test nt = test_node4(q0, q1, q2, q3, w.o, w.inv, tfar, refs);
+      Node4Test nt = test_node4(q0, q1, q2, q3, w.o, w.inv, w.tmin, tfar, refs);
       int next = kTraversalDone;
       if (nt.hit[3]) next = refs.w;
       if (nt.hit[2]) {

@@ -82,6 +82,47 @@ def test_closest_hit_bit_exact(name, oracle, rtx_lib):
             assert_same_hits(got, want)
 
 
+@pytest.mark.parametrize("name", ["cornell", "terrain", "soup", "huge_quad"])
+def test_hits_at_distances_around_eps(name, oracle, rtx_lib):
+    """The walk skips boxes the ray has left before eps / 2 (a hit needs eps < t): rays that start a
+    fraction or a small multiple of eps in front of a surface, head-on and grazing, must still find
+    exactly the hits the linear scan finds -- the ones whose computed t just passes eps included --
+    and the same occlusion answers, on thin axis-aligned quads, a fine terrain, a soup and a quad
+    thousands of units wide (whose computed t is noisy at the scale of eps)."""
+    def huge_quad():   # the 2000-unit ground quad of the sphere scenes with enough small triangles on it for a tree
+        g, small = scenes.sphere_sky(), scenes.soup(40, 0, seed=8, size=0.3)
+        return scenes.SceneData(np.concatenate([g.triangles, small.triangles]), np.zeros(42, np.uint32), g.materials,
+                                g.spheres, name="huge_quad")
+    sc = {"cornell": scenes.cornell, "terrain": lambda: scenes.terrain(40), "soup": lambda: scenes.soup(3000, 0, seed=6),
+          "huge_quad": huge_quad}[name]()
+    cfg = Config(width=256, height=256, sky=1, pool_paths=1 << 14)
+    osc = oracle.OracleScene(sc, cfg)
+    primary = camera_rays(oracle, cfg, 40)
+    kind, prim, t, nrm = osc.trace_closest(primary)
+    hit = kind == 1
+    p = (primary[hit, :3] + primary[hit, 3:] * t[hit, None]).astype(np.float32)
+    n = nrm[hit]
+    rng = np.random.default_rng(17)
+    rays = []
+    for scale in (0.3, 0.45, 0.5, 0.55, 0.9, 0.999, 1.0, 1.001, 1.1, 2.0, 5.0):
+        d = rng.normal(size=p.shape)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        graze = rng.random(len(p)) < 0.5                   # half of them nearly in the surface's plane
+        along = np.sum(d * n, 1, keepdims=True)
+        d = np.where(graze[:, None], d - 0.98 * along * n, d)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        o = p - d * np.float32(scale * cfg.eps)             # the surface lies scale * eps ahead (or behind, for rays leaving it)
+        rays.append(np.concatenate([o, d], 1))
+        rays.append(np.concatenate([p + d * np.float32(scale * cfg.eps), -d], 1))
+    rays = np.concatenate(rays).astype(np.float32)
+    dist = rng.uniform(0.0, 6.0 * cfg.eps, rays.shape[0]).astype(np.float32)
+    dist[::3] = rng.uniform(0.0, 3.0, len(dist[::3])).astype(np.float32)
+    with Renderer(cfg) as r:
+        r.set_scene(sc)
+        assert_same_hits(r.trace_closest(rays), osc.trace_closest(rays, use_bvh=False))
+        assert np.array_equal(r.trace_occluded(rays, dist), osc.trace_occluded(rays, dist, use_bvh=False))
+
+
 def test_two_child_tree_in_global_memory(oracle, rtx_lib, monkeypatch):
     """A small scene whose tree is too deep for the LDS budget keeps its two-child tree in global
     memory.  RTX_NO_LDS_SCENE forces that mode for an ordinary small scene: same hits, same
