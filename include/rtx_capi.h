@@ -155,6 +155,9 @@ typedef struct {
   uint64_t truncated_paths;  /* paths the drain kernel gave up on after 65536 bounces (the reference's loop
                                 has no bound, Integrator.h:108; at rr_cap 0.99 such a path has probability
                                 below 1e-286); their colour so far is stored as if they had ended */
+  uint64_t drain_launches;   /* chunks that ended in the drain kernel (one launch that runs the last paths to
+                                their ends) */
+  uint64_t overlapped_sums;  /* ... of which the ordered sum ran beside that kernel on a second stream */
 } rtx_stats;
 
 typedef struct {

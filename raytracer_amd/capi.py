@@ -76,6 +76,7 @@ class Stats(C.Structure):
         ("timed_launches_intersect", C.c_uint64), ("timed_launches_shade", C.c_uint64),
         ("timed_launches_shadow", C.c_uint64), ("timed_launches_generate", C.c_uint64),
         ("nan_paths", C.c_uint64), ("truncated_paths", C.c_uint64),
+        ("drain_launches", C.c_uint64), ("overlapped_sums", C.c_uint64),
     ]
 
     def as_dict(self) -> dict:

@@ -250,6 +250,7 @@ struct rtx_ctx {
   bool pending = false;             // a frame is in flight whose summary has not been absorbed
   const float* pending_accum = nullptr;
   uint64_t pending_iterations = 0, pending_launches = 0;
+  bool pending_drained = false;
   int next_set = 0;
 };
 
@@ -729,7 +730,7 @@ uint32_t div_up(uint32_t n, uint32_t d) { return n == 0 ? 1u : (n + d - 1) / d; 
 // Renders samples [sample_base, sample_base+spp) of the band into the result
 // buffer and folds them into accum.  One chunk = one fill/drain of the queues.
 // Takes the summary of a finished chunk (in h_sum[0]) into the statistics.
-int absorb_summary(rtx_ctx* c, uint64_t iterations, uint64_t launches) {
+int absorb_summary(rtx_ctx* c, uint64_t iterations, uint64_t launches, bool drained, bool overlapped) {
   const rtx::Summary& h = c->h_sum[0];
   if (h.next_sample != h.total_samples)
     return fail(RTX_ERR_HIP, "rtx_render: internal error, samples left ungenerated");
@@ -742,6 +743,8 @@ int absorb_summary(rtx_ctx* c, uint64_t iterations, uint64_t launches) {
   st.truncated_paths += h.stat_truncated;
   st.iterations += iterations;
   st.launches += launches;
+  st.drain_launches += drained ? 1 : 0;
+  st.overlapped_sums += overlapped ? 1 : 0;
   return RTX_OK;
 }
 
@@ -752,7 +755,7 @@ int finish_pending(rtx_ctx* c) {
   c->pending_accum = nullptr;
   HIP_TRY(hipEventSynchronize(c->ev_done));
   HIP_TRY(hipGetLastError());
-  return absorb_summary(c, c->pending_iterations, c->pending_launches);
+  return absorb_summary(c, c->pending_iterations, c->pending_launches, c->pending_drained, false);
 }
 // ... on either set (accum == nullptr), or for the frames that add to `accum`.
 int wait_frames(rtx_ctx* c, const float* accum) {
@@ -988,7 +991,6 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
       poll_pending--;
     }
   }
-  (void)finished;
   // Fold the chunk's samples into the sums, in sample order.
   if (after_reduce) HIP_TRY(hipStreamWaitEvent(st, after_reduce, 0));
   lt.begin(kReduce, total);
@@ -1008,11 +1010,12 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
     c->pending = true;
     c->pending_iterations = iterations;
     c->pending_launches = launches;
+    c->pending_drained = finished;
     return RTX_OK;
   }
   HIP_TRY(hipStreamSynchronize(st));
   HIP_TRY(hipGetLastError());
-  return absorb_summary(c, iterations, launches);
+  return absorb_summary(c, iterations, launches, finished, reduce_split);
 }
 
 }  // namespace

@@ -222,16 +222,16 @@ def test_sum_beside_the_drain_kernel_keeps_the_bits(finish_paths, rtx_lib, monke
             kw = dict(width=128, height=96, sky=sky, pool_paths=1 << 14, finish_paths=finish_paths)
             img, st, _ = gpu_render(Config(**kw), sc, 12, calls=[dict(spp=7), dict(spp=5, sample_base=7)])
             band, _, _ = gpu_render(Config(**kw), sc, 6, calls=[dict(spp=6, row0=8, row1=40)])
-            out.append((img, band, st.bounces, st.launches))
+            out.append((img, band, st.bounces, st.drain_launches, st.overlapped_sums))
         monkeypatch.delenv("RTX_OVERLAP_MIN_SAMPLES")
         assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
         assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
         assert out[0][2] == out[1][2]
         # The drain kernel runs only if a snapshot of the queue reaches the host between "samples exhausted, at
-        # most finish_paths paths left" and "no path left", which depends on timing for renders this small: the
-        # split sum (two more launches per chunk) may or may not run in a given chunk.
-        assert out[0][3] >= out[1][3]
-        split_ran = split_ran or out[0][3] > out[1][3]
+        # most finish_paths paths left" and "no path left", which depends on timing for renders this small; the
+        # sum runs beside it whenever it does (forced on), never when forced off.
+        assert out[0][4] == out[0][3] and out[1][4] == 0
+        split_ran = split_ran or out[0][4] > 0
     if finish_paths == 1 << 20:
         assert split_ran                       # with the drain kernel taking over at once it ran for some chunk
 
