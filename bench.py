@@ -409,8 +409,8 @@ def run_leg(args, workload, world, rank, local_rank, steps, warmup, profile, tor
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="sample2_glass")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel")
     ap.add_argument("--width", type=int, default=0)
