@@ -78,3 +78,48 @@ def test_frames_in_flight_with_chunks_and_a_scene_change(rtx_lib):
             out[mode] = images
         for x, y in zip(out["sync"], out["async"]):
             assert np.array_equal(bits(x), bits(y))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_interleavings_of_frames_in_flight(seed, rtx_lib):
+    """Random programmes of asynchronous and synchronous frames into three buffers, with waits on one
+    buffer, waits on all, ray queries (which share the traversal stacks' spill columns with the frames)
+    and statistics reads thrown in: every buffer ends with the bits of the same frames rendered one
+    after the other, and the path counts add up."""
+    rng = np.random.default_rng(1000 + seed)
+    sc = [scenes.cornell(), scenes.sphere_sky(glass=True), scenes.soup(3000, 2, seed=3)][seed % 3]
+    cfg = Config(width=96, height=64, sky=int(seed % 3 != 0), pool_paths=int(rng.choice([1 << 11, 1 << 13])),
+                 finish_paths=int(rng.choice([0, 64, 1 << 20])))
+    rays = scenes.random_rays(500, seed=seed)
+    with Renderer(cfg) as r, Renderer(cfg) as ref:
+        r.set_scene(sc)
+        ref.set_scene(sc)
+        bufs = [r.accum_alloc() for _ in range(3)]
+        refs = [ref.accum_alloc() for _ in range(3)]
+        done = [0, 0, 0]               # samples each buffer holds
+        for step in range(int(rng.integers(8, 16))):
+            b = int(rng.integers(0, 3))
+            spp = int(rng.integers(1, 4))
+            op = rng.random()
+            if op < 0.6:
+                r.render_async(bufs[b], spp, sample_base=done[b])
+            elif op < 0.8:
+                r.render(bufs[b], spp, sample_base=done[b])
+            else:
+                spp = 0
+                what = int(rng.integers(0, 4))
+                if what == 0:
+                    r.wait(bufs[b])
+                elif what == 1:
+                    r.wait()
+                elif what == 2:
+                    r.trace_closest(rays)
+                else:
+                    r.stats()
+            if spp:
+                ref.render(refs[b], spp, sample_base=done[b])
+                done[b] += spp
+        for b in range(3):
+            assert np.array_equal(bits(r.resolve(bufs[b], 1)), bits(ref.resolve(refs[b], 1))), (seed, b)
+        st, st_ref = r.stats(), ref.stats()
+        assert (st.paths, st.bounces, st.shadow_rays) == (st_ref.paths, st_ref.bounces, st_ref.shadow_rays)
