@@ -239,21 +239,47 @@ __device__ __forceinline__ float tri_intersect_n(f3 a, f3 ba, f3 ca, f3 n, f3 o,
 __device__ __forceinline__ float tri_intersect(f3 a, f3 ba, f3 ca, f3 o, f3 d) {
   return tri_intersect_n(a, ba, ca, vcross(ba, ca), o, d);
 }
-// Triangle `slot` against a ray.  The record carries the normal (b-a)x(c-a),
-// computed on the host with the same float operations (no contraction on either
-// side), so the lanes do not recompute it; it shares the record's 64-byte line.
+// What consecutive triangles of a leaf can share.  The two triangles of a quad (a, b, c), (a, c, d) have the
+// same first vertex, so o - a and (o - a) x d are the same floats for both; where their stored normals are
+// equal as well (any axis-aligned rectangle), so are 1/(d.n) and t.  The host compares the records and sets
+// the flags in a record's third row (kSameVertex, kSamePlane: relative to the record before it); the lanes
+// then skip the operations whose results they still hold, and every hit keeps the bits a full test gives.
+struct TriCarry {
+  f3 roa, q;
+  float inv, t;
+};
+constexpr uint32_t kSameVertex = 1u;  // first vertex equals the previous record's
+constexpr uint32_t kSamePlane = 2u;   // and so does the normal (zero components may differ in sign)
+// Triangle `slot` against a ray: Triangle::intersect, reference Obj.h:110-121, as tri_intersect_n.  The record
+// carries the normal (b-a)x(c-a), computed on the host with the same float operations (no contraction on
+// either side), so the lanes do not recompute it; it shares the record's 64-byte line.  `reuse`: the lane
+// tested the record before this one with the same ray and `s` still holds what that test left.
 template <bool LDS_COPY = true>
-__device__ __forceinline__ float tri_test(const Geom& g, uint32_t slot, f3 o, f3 d, uint32_t& prim) {
+__device__ __forceinline__ float tri_test(const Geom& g, uint32_t slot, bool reuse, f3 o, f3 d, TriCarry& s,
+                                          uint32_t& prim) {
   const float4* r = g.tris + g.stride * (size_t)slot;
   float4 A = r[0], B = r[1], C = r[2], N = r[3];
 #if RTX_FULL_RECORD_READS
   if constexpr (LDS_COPY)
   // keeps the reads 16 bytes wide: the unused fourth components would otherwise turn them into
   // 12-byte LDS reads, which take twice the LDS cycles of a 16-byte one
-  asm volatile("" ::"v"(B.w), "v"(C.w), "v"(N.w));
+  asm volatile("" ::"v"(B.w), "v"(N.w));
 #endif
   prim = __float_as_uint(A.w);
-  return tri_intersect_n(mk3(A.x, A.y, A.z), mk3(B.x, B.y, B.z), mk3(C.x, C.y, C.z), mk3(N.x, N.y, N.z), o, d);
+  const uint32_t shared = reuse ? __float_as_uint(C.w) : 0u;
+  const f3 ba = mk3(B.x, B.y, B.z), ca = mk3(C.x, C.y, C.z), n = mk3(N.x, N.y, N.z);
+  if (!(shared & kSameVertex)) {
+    s.roa = vsub(o, mk3(A.x, A.y, A.z));
+    s.q = vcross(s.roa, d);
+  }
+  if (!(shared & kSamePlane)) {
+    s.inv = 1.0f / vdot(d, n);
+    s.t = s.inv * -vdot(n, s.roa);
+  }
+  float u = s.inv * -vdot(s.q, ca);
+  float v = s.inv * vdot(s.q, ba);
+  if (u < 0.0f || u > 1.0f || v < 0.0f || (u + v) > 1.0f) return INFINITY;
+  return s.t;
 }
 
 // Sphere::intersect, reference Obj.h:257-268.
@@ -329,10 +355,11 @@ template <int MODE>
 __device__ __forceinline__ void leaf_closest(const Geom& g, uint32_t leaf, f3 o, f3 d, float eps,
                                              float& best_t, uint32_t& best_prim, uint32_t& best_slot) {
   uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
+  TriCarry carry;
   for (uint32_t k = 0; k < cnt; k++) {
     uint32_t slot = first + k;
     uint32_t prim;
-    float t = tri_test<MODE != kFewTriangles>(g, slot, o, d, prim);
+    float t = tri_test<MODE != kFewTriangles>(g, slot, k != 0, o, d, carry, prim);
     if (eps < t && t < INFINITY && (t < best_t || (t == best_t && prim < best_prim))) {
       best_t = t;
       best_prim = prim;
@@ -346,10 +373,11 @@ template <int MODE>
 __device__ __forceinline__ bool leaf_any(const Geom& g, uint32_t leaf, f3 o, f3 d, float eps, float tfar) {
   uint32_t first = leaf >> 3, cnt = (leaf & 7u) + 1u;
   bool hit = false;
+  TriCarry carry;
   for (uint32_t k = 0; k < cnt; k++) {
     uint32_t slot = first + k;
     uint32_t prim;
-    float t = tri_test<MODE != kFewTriangles>(g, slot, o, d, prim);
+    float t = tri_test<MODE != kFewTriangles>(g, slot, k != 0, o, d, carry, prim);
     if (eps < t && t < tfar) hit = true;
   }
   return hit;

@@ -501,10 +501,26 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
     std::memcpy(&fmi, &mi, 4);
     tr[4 * slot] = make_float4(p[0], p[1], p[2], fprim);
     tr[4 * slot + 1] = make_float4(bax, bay, baz, fmi);
-    tr[4 * slot + 2] = make_float4(cax, cay, caz, 0.f);
     // (b-a)x(c-a) with the operations of the device's cross product (no contraction on either side)
     const float nx = bay * caz - baz * cay, ny = baz * cax - bax * caz, nz = bax * cay - bay * cax;
     tr[4 * slot + 3] = make_float4(nx, ny, nz, 0.f);
+    // What this record shares with the one before it (the walk looks at the flags only for the second and later
+    // triangles of a leaf): the two halves of a quad have the same first vertex, bit for bit, and those of an
+    // axis-aligned rectangle the same normal.  The normals are compared as floats, so a zero component may
+    // differ in sign (the cross products of a rectangle's halves give (4, 0, 0) and (4, -0, 0)): x + 0 and
+    // x + -0 are the same float for every x that is not itself a zero, so d.n and n.(o-a) come out the same
+    // bits unless they are zero, and a zero d.n (t infinite or NaN) or a zero n.(o-a) (t = 0, not beyond eps) is
+    // no hit with either sign.
+    uint32_t shared = 0;
+    if (slot > 0) {
+      const float4 &pa = tr[4 * slot - 4], &pn = tr[4 * slot - 1];
+      const float prev[3] = {pa.x, pa.y, pa.z};
+      if (std::memcmp(prev, p, 12) == 0)
+        shared = (pn.x == nx && pn.y == ny && pn.z == nz) ? (rtx::kSameVertex | rtx::kSamePlane) : rtx::kSameVertex;
+    }
+    float fshared;
+    std::memcpy(&fshared, &shared, 4);
+    tr[4 * slot + 2] = make_float4(cax, cay, caz, fshared);
     // The shading normal of a mesh hit, normalize(Ng) (Scene.h:181-187, Vec3.cpp:24-30): the square
     // root of ((x*x + y*y) + z*z), then three divisions; the same IEEE operations the device would
     // perform per hit, done once here (this file is compiled without contraction as well).
