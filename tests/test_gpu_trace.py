@@ -191,6 +191,72 @@ def test_meshes_of_a_few_triangles_are_tested_without_a_tree(oracle, rtx_lib, mo
         assert out["few"][3].bounces == out["tree"][3].bounces
 
 
+def test_triangles_that_share_a_vertex_or_a_plane(oracle, rtx_lib):
+    """Consecutive triangles of a leaf reuse what they share: o-a and (o-a)xd when the first vertex is the same,
+    1/(d.n) and t as well when the normals are equal (as floats: the halves of an axis-aligned rectangle give
+    (4, 0, 0) and (4, -0, 0)).  Fans around one vertex whose triangles lie in one plane, in two, or in planes that
+    differ in a last bit, as a mesh of up to eight triangles (one run of eight records) and with a ninth triangle
+    (leaves of two in a tree): rays in the planes, starting on them, along the axes and at random must give the
+    linear scan's hits and occlusion answers bit for bit."""
+    rng = np.random.default_rng(23)
+
+    def fan(center, rim):
+        return [np.concatenate([center, rim[i], rim[i + 1]]) for i in range(len(rim) - 1)]
+
+    c = np.array([0.1, 0.5, -0.2])
+    flat = [c + np.array([np.cos(a), 0.0, np.sin(a)]) * r for a, r in zip(np.linspace(0, 4.5, 6), (1.0, 0.7, 1.2, 0.9, 1.1, 0.8))]
+    bent = [p + np.array([0.0, 0.3 * (i % 2), 0.0]) for i, p in enumerate(flat)]
+    angle = np.radians(17.0)   # a rotated rectangle: the normals of its halves differ in the last bits, or not at all
+    u, v = np.array([np.cos(angle), 0.0, np.sin(angle)]) * 0.8, np.array([0.0, 1.3, 0.0])
+    meshes = {
+        "rectangles": np.concatenate([scenes.quad((-1, 0, -1), (1, 0, -1), (1, 0, 1), (-1, 0, 1)),
+                                      scenes.quad((-1, 0, -1), (-1, 2, -1), (-1, 2, 1), (-1, 0, 1)),
+                                      scenes.quad((1, 2, 1), (-1, 2, 1), (-1, 0, 1), (1, 0, 1)),
+                                      scenes.quad(c, c + u, c + u + v, c + v)]),
+        "flat_fan": np.array(fan(c, flat), np.float32),
+        "bent_fan": np.array(fan(c, bent), np.float32),
+        "mixed_fan": np.array(fan(c, flat[:3] + bent[3:]) + fan(c + 0.5, flat[:3]), np.float32),
+    }
+    extra = np.array([[3.0, 0.0, 3.0, 3.5, 0.0, 3.0, 3.0, 0.5, 3.5]], np.float32)   # a ninth triangle: the tree takes over
+    for name, tris in meshes.items():
+        for with_tree in (False, True):
+            t = np.concatenate([tris, extra]) if with_tree and len(tris) <= 8 else tris
+            sc = scenes.SceneData(t.astype(np.float32), np.zeros(len(t), np.uint32),
+                                  np.array([scenes.material(scenes.WHITE)], scenes.MATERIAL_DTYPE))
+            cfg = Config(width=64, height=64, pool_paths=1 << 12)
+            osc = oracle.OracleScene(sc, cfg)
+            tri = t.reshape(-1, 3, 3).astype(np.float64)
+            rays = [scenes.random_rays(6000, seed=31, origin_box=((-2, -1, -2), (2, 3, 2)))]
+            # from points on the triangles (t = 0 for the triangle itself), towards other points on them (rays in the plane
+            # of a flat fan) and at random
+            w = rng.dirichlet((1, 1, 1), (2, 3000))
+            k = rng.integers(0, len(tri), (2, 3000))
+            on = [(w[i][:, :, None] * tri[k[i]]).sum(1) for i in range(2)]
+            d = on[1] - on[0]
+            d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-9)
+            rays.append(np.concatenate([on[0], d], 1))
+            r2 = rng.normal(size=(3000, 3))
+            rays.append(np.concatenate([on[1], r2 / np.linalg.norm(r2, axis=1, keepdims=True)], 1))
+            start = on[1] + r2   # aimed at the triangles from outside
+            aim = on[0] - start
+            rays.append(np.concatenate([start, aim / np.linalg.norm(aim, axis=1, keepdims=True)], 1))
+            for axis in range(3):   # axis-parallel: d.n = 0 for the rectangles beside the ray, products with signed zeros
+                for sign in (1.0, -1.0):
+                    o = rng.uniform(-1.5, 2.5, (400, 3))
+                    o[:200] = on[0][:200]
+                    dd = np.zeros((400, 3))
+                    dd[:, axis] = sign
+                    rays.append(np.concatenate([o, dd], 1))
+            rays = np.concatenate(rays).astype(np.float32)
+            dist = rng.uniform(0.0, 3.0, len(rays)).astype(np.float32)
+            with Renderer(cfg) as r:
+                r.set_scene(sc)
+                want = osc.trace_closest(rays, use_bvh=False)
+                assert_same_hits(r.trace_closest(rays), want)
+                assert np.array_equal(r.trace_occluded(rays, dist), osc.trace_occluded(rays, dist, use_bvh=False)), name
+            assert (want[0] != 0).sum() > 2000, name
+
+
 @pytest.mark.parametrize("name", ["cornell", "soup10k", "sphere_sky", "spheres_only", "ref_scene0", "ref_scene1"])
 def test_occlusion_bit_exact(name, oracle, rtx_lib):
     cfg = Config(width=800, height=800, pool_paths=1 << 16)
