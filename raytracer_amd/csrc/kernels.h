@@ -438,14 +438,14 @@ __device__ __forceinline__ f3 fast_safe_inverse(f3 d) {
   return mk3(__builtin_amdgcn_rcpf(x), __builtin_amdgcn_rcpf(y), __builtin_amdgcn_rcpf(z));
 }
 __device__ __forceinline__ void order2(float& ta, int& ra, float& tb, int& rb) {
-  if (tb < ta) {
-    float t = ta;
-    ta = tb;
-    tb = t;
-    int r = ra;
-    ra = rb;
-    rb = r;
-  }
+  // selects, not a branch around four moves: one comparison and four conditional moves, no mask bookkeeping
+  const bool s = tb < ta;
+  const float lo = s ? tb : ta, hi = s ? ta : tb;
+  const int rl = s ? rb : ra, rh = s ? ra : rb;
+  ta = lo;
+  tb = hi;
+  ra = rl;
+  rb = rh;
 }
 
 // Traversal state of one ray.  `cur` is the node (>= 0) or leaf (< 0, ~leaf word)
