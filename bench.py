@@ -209,18 +209,18 @@ def build_roofline(workload, stage, fused):
             lanes = sq["SQ_THREAD_CYCLES_VALU"] / sq["SQ_ACTIVE_INST_VALU"]
     fr = [f for f in (hbm_frac, valu_frac) if f is not None]
     if not fr:
-        bound = "hbm"
+        bound = "unmeasured"   # no counter files for this workload under profiles/: the byte model alone bounds nothing
     elif max(fr) < 0.5:
         bound = "latency"
     else:
         bound = "hbm" if (hbm_frac or 0) >= (valu_frac or 0) else "valu"
     roof = {
         "bound": bound, "kernel": prefix,
-        "achieved": round(hbm_gbs, 2) if hbm_gbs else round(alg_gbs, 2),
+        "achieved": round(hbm_gbs, 2) if hbm_gbs else None,
         "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round((hbm_gbs if hbm_gbs else alg_gbs) / HBM_PEAK_GBS, 5),
+        "frac": round(hbm_gbs / HBM_PEAK_GBS, 5) if hbm_gbs else None,
         "achieved_is": "counter HBM bytes per launch / live launch duration" if hbm_gbs else
-                       "algorithmic bytes per launch / live launch duration (no counter file for this workload)",
+                       "not measured: no counter file for this workload (see `algorithmic` for the byte model)",
         "traffic": traffic, "traffic_source": traffic_src,
         "avg_launch_ms": round(avg_ms, 5), "launches": int(launches),
         "units_per_launch": round(units / launches, 1),
