@@ -1290,6 +1290,16 @@ __global__ __launch_bounds__(1024) void k_plan(SegCounter* seg, Summary* sum, in
   __shared__ uint32_t wave_part[16][5];
   const uint32_t s = threadIdx.x, lane = s & 63u, wave = s >> 6, nwaves = blockDim.x >> 6;
   uint32_t n = 0, sh = 0, ne = 0, drained = 0, room = 0;
+  // Everything this block reads is requested here, ahead of the first barrier, so that the loads share one
+  // round trip (the kernel is a chain of dependent steps between two rounds with the whole chip waiting on it).
+  const unsigned long long next = sum->next_sample, total = sum->total_samples;
+  unsigned long long stat_paths = 0, stat_bounces = 0, stat_shadow = 0, stat_nee = 0;
+  if (s == 0) {
+    stat_paths = sum->stat_paths;
+    stat_bounces = sum->stat_bounces;
+    stat_shadow = sum->stat_shadow;
+    stat_nee = sum->stat_nee;
+  }
   if (s < nseg) {
     unsigned long long c = seg[s].c[qf];
     n = seg_paths(c);
@@ -1311,7 +1321,6 @@ __global__ __launch_bounds__(1024) void k_plan(SegCounter* seg, Summary* sum, in
     if (w < wave) before_wave += wave_room[w];
     room_total += wave_room[w];
   }
-  const unsigned long long next = sum->next_sample, total = sum->total_samples;
   const unsigned long long left = total - next;
   const unsigned long long before_room = before_wave + incl - room;
   const unsigned long long before = before_room < left ? before_room : left;
@@ -1355,10 +1364,10 @@ __global__ __launch_bounds__(1024) void k_plan(SegCounter* seg, Summary* sum, in
       drained_total += wave_part[w][4];
     }
     sum->next_sample = next + gen_total;
-    sum->stat_paths += gen_total;
-    sum->stat_bounces += drained_total;
-    sum->stat_shadow += shadow_total;
-    sum->stat_nee += nee_total;
+    sum->stat_paths = stat_paths + gen_total;
+    sum->stat_bounces = stat_bounces + drained_total;
+    sum->stat_shadow = stat_shadow + shadow_total;
+    sum->stat_nee = stat_nee + nee_total;
     sum->active_total = (uint32_t)((unsigned long long)nseg * cap - room_total + gen_total);
     sum->active_max = fill_max;
   }
