@@ -999,6 +999,32 @@ __device__ __forceinline__ void wave_append(bool take_path, bool take_shadow, bo
                __builtin_amdgcn_mbcnt_hi((uint32_t)(ms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ms, 0u));
 }
 
+// wave_append in two halves, for a caller that only appends paths (no light samples) and has work to do between
+// reserving the slots and filling them: the atomic's round trip then runs beside that work.  The counter's old
+// value stays in lane 0's register until wave_path_slot asks for it.
+struct PathTicket {
+  unsigned long long mask;  // lanes that take a slot
+  uint32_t old_lo;          // low word of the counter before the reservation (lane 0)
+};
+__device__ __forceinline__ PathTicket wave_reserve_paths(bool take_path, unsigned long long* counter) {
+  PathTicket tk;
+  tk.mask = __ballot(take_path);
+  tk.old_lo = 0;
+  if (tk.mask != 0) {
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    // (the path count is the counter's low field, so a 32-bit add to its low word is the same addition; its
+    // answer is one register, where the unused high word of a 64-bit answer would be handed to the code that
+    // follows as a free register, and the first write to it would wait for the atomic)
+    if (lane == 0) tk.old_lo = atomicAdd(reinterpret_cast<uint32_t*>(counter), (uint32_t)__popcll(tk.mask));
+  }
+  return tk;
+}
+__device__ __forceinline__ uint32_t wave_path_slot(const PathTicket& tk) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk.old_lo);
+  return (lo & (uint32_t)kFieldMask) +
+         __builtin_amdgcn_mbcnt_hi((uint32_t)(tk.mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tk.mask, 0u));
+}
+
 // ----------------------------------------------------------------------------
 // One bounce of pathTrace.
 
@@ -1108,15 +1134,19 @@ __device__ __forceinline__ void store_path(const SceneDev& sc, const Queue& q, u
   if (sc.max_bounces) q.depth[i] = p.depth;
 }
 
-// The body of the loop at reference Integrator.h:108-285 for a path whose
-// closest hit (t, id) is known.  Returns true when the path goes on (p then holds
-// the next ray); `want_shadow` asks for the NEE segment in `sr` to be tested for
-// occlusion before its contribution is added to the path's colour.
-__device__ __forceinline__ bool shade_bounce(const SceneDev& sc, const Geom& g, PathState& p, float t,
-                                             uint32_t id, bool& want_shadow, bool& did_nee, ShadowReq& sr,
-                                             LastSphere* last = nullptr) {
-  want_shadow = false;
-  did_nee = false;
+// The body of the loop at reference Integrator.h:108-285 for a path whose closest hit (t, id) is known, in two
+// halves.  shade_arrive: miss, surface lookup, emission, Russian roulette (:113-194); returns true when the
+// path goes on.  shade_leave: the surface's switch (:196-278), after which p holds the next ray; `want_shadow`
+// asks for the NEE segment in `sr` to be tested for occlusion before its contribution is added to the path's
+// colour.  Whether a path goes on is known after the first half: a caller can reserve its queue slot there.
+struct SurfaceHit {
+  f3 n3, albedo;
+  float emis;
+  int surface;
+};
+template <bool SETTLE = false>
+__device__ __forceinline__ bool shade_arrive(const SceneDev& sc, const Geom& g, PathState& p, float t, uint32_t id,
+                                             SurfaceHit& h, LastSphere* last = nullptr) {
   if (sc.max_bounces) p.depth++;
   if (id == kMiss) {  // Integrator.h:113-116
     if (sc.sky || sc.integrator == 1) {
@@ -1129,6 +1159,14 @@ __device__ __forceinline__ bool shade_bounce(const SceneDev& sc, const Geom& g, 
   float emis;
   int surface;
   hit_surface(sc, g, id, p.o, p.d, t, n3, albedo, emis, surface, last);
+  h.n3 = n3;
+  h.albedo = albedo;
+  h.emis = emis;
+  h.surface = surface;
+  // SETTLE: every load of the lookup has landed when this half returns.  A wait for one of them further down
+  // would be a wait for everything issued in between as well, a caller's early reservation included.
+  if constexpr (SETTLE)
+    asm volatile("" ::"v"(surface), "v"(albedo.x), "v"(albedo.y), "v"(albedo.z), "v"(n3.x), "v"(n3.y), "v"(n3.z));
   if (sc.integrator == 1) {  // rayTraceNormals, Integrator.h:87-96
     p.col = vadd(vscale(n3, 0.5f), splat3(0.5f));
     return false;
@@ -1150,6 +1188,14 @@ __device__ __forceinline__ bool shade_bounce(const SceneDev& sc, const Geom& g, 
   if (pcg_uniform(p.rng) > pr) return false;
   if (sc.max_bounces && p.depth >= sc.max_bounces) return false;
   p.att = vdivs(p.att, pr);
+  return true;
+}
+__device__ __forceinline__ void shade_leave(const SceneDev& sc, PathState& p, const SurfaceHit& h, bool& want_shadow,
+                                            bool& did_nee, ShadowReq& sr) {
+  f3 n3 = h.n3;
+  const f3 albedo = h.albedo;
+  const float emis = h.emis;
+  const int surface = h.surface;
   if (surface == 2) {  // reflective, :198-205
     float cos_t = vdot(p.d, n3);
     p.d = vsub(p.d, vscale(vscale(n3, cos_t), 2.0f));
@@ -1226,6 +1272,15 @@ __device__ __forceinline__ bool shade_bounce(const SceneDev& sc, const Geom& g, 
     p.mis_pdf = -1.0f;
   }
   // varnish: the reference's switch has no case for it; nothing changes.
+}
+__device__ __forceinline__ bool shade_bounce(const SceneDev& sc, const Geom& g, PathState& p, float t,
+                                             uint32_t id, bool& want_shadow, bool& did_nee, ShadowReq& sr,
+                                             LastSphere* last = nullptr) {
+  want_shadow = false;
+  did_nee = false;
+  SurfaceHit h;
+  if (!shade_arrive(sc, g, p, t, id, h, last)) return false;
+  shade_leave(sc, p, h, want_shadow, did_nee, sr);
   return true;
 }
 
@@ -1657,7 +1712,7 @@ __global__ __launch_bounds__(256) void k_shade_wave_append(SceneDev sc, Queue in
 // bounce and the hit stays in registers.
 // (eight waves per SIMD: the compiler then keeps to 96 scalar registers as well, which it passed by five
 // otherwise, and a wave of this kernel mostly waits: sample2 8.8 -> 8.3 ms, Cornell's bounces 51.7 -> 49.4)
-template <int BLOCK, int MODE>
+template <int BLOCK, int MODE, bool LIGHTS>
 __global__ __launch_bounds__(BLOCK, 8) void k_trace_shade(SceneDev sc, Queue in, Queue out, ShadowQueue sq,
                                                        SegCounter* seg, int qi, uint32_t cap, float* res,
                                                        TraceParams tp, const Primary* __restrict__ prp, Summary* sum) {
@@ -1671,21 +1726,33 @@ __global__ __launch_bounds__(BLOCK, 8) void k_trace_shade(SceneDev sc, Queue in,
 
   PathState p;
   ShadowReq sr;
+  SurfaceHit sh;
   bool alive = false, want_shadow = false, did_nee = false, bad = false;
+  // Without lights a bounce queues no light sample, so the append counts paths only, and which paths go on is
+  // known once the roulette is through: the slots are reserved there and the atomic's round trip runs beside
+  // the sampling of the next direction.
+  constexpr bool reserve_early = !LIGHTS;  // (LIGHTS: the scene has any, sc.num_lights != 0)
   if (active) {
     load_path(sc, in, i, j >= seg[s].gen_slot0, *prp, (uint32_t)seg[s].gen_ordinal0 + (j - seg[s].gen_slot0), p);
     float t;
     uint32_t id;
     cast_ray<MODE>(sc, geom, p.o, p.d, stk, t, id);
-    alive = shade_bounce(sc, global_geom(sc), p, t, id, want_shadow, did_nee, sr);
+    alive = reserve_early ? shade_arrive<true>(sc, global_geom(sc), p, t, id, sh)
+                          : shade_bounce(sc, global_geom(sc), p, t, id, want_shadow, did_nee, sr);
     if (!alive) {
       store_result(res, p.ordinal, p.col);
       bad = colour_not_finite(p.col);
     }
   }
   wave_count(bad, &sum->stat_nan);
-  uint32_t pos, spos;  // (the per-block append of k_shade_block_append measured slower here)
-  wave_append(alive, want_shadow, did_nee, &seg[s].c[qi ^ 1], pos, spos);
+  uint32_t pos, spos = 0;  // (the per-block append of k_shade_block_append measured slower here)
+  if (reserve_early) {
+    const PathTicket tk = wave_reserve_paths(alive, &seg[s].c[qi ^ 1]);
+    if (alive) shade_leave(sc, p, sh, want_shadow, did_nee, sr);
+    pos = wave_path_slot(tk);
+  } else {
+    wave_append(alive, want_shadow, did_nee, &seg[s].c[qi ^ 1], pos, spos);
+  }
   if (alive) store_path(sc, out, s * cap + pos, p);
   if (want_shadow) {
     const uint32_t k = s * cap + spos;

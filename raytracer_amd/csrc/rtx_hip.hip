@@ -919,15 +919,23 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
     const uint32_t gx256 = div_up(seg_max_upper, 256);
     if (fused) {
       lt.begin(kShade, active_upper);
+      // (two builds of each: with lights a bounce queues light samples, without it reserves its queue slots early)
+#define RTX_TRACE_SHADE(B, M, LDS)                                                                                \
+  do {                                                                                                            \
+    if (c->scene.num_lights != 0)                                                                                 \
+      rtx::k_trace_shade<B, M, true><<<dim3(div_up(seg_max_upper, B), nseg), B, LDS, st>>>(                       \
+          c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp, sum);                                           \
+    else                                                                                                          \
+      rtx::k_trace_shade<B, M, false><<<dim3(div_up(seg_max_upper, B), nseg), B, LDS, st>>>(                      \
+          c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp, sum);                                           \
+  } while (0)
       if (few)
-        rtx::k_trace_shade<128, rtx::kFewTriangles><<<dim3(div_up(seg_max_upper, 128), nseg), 128, 0, st>>>(
-            c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp, sum);
+        RTX_TRACE_SHADE(128, rtx::kFewTriangles, 0);
       else if (fused_block == 128)
-        rtx::k_trace_shade<128, rtx::kLdsBvh2><<<dim3(div_up(seg_max_upper, 128), nseg), 128, lds_fused, st>>>(
-            c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp, sum);
+        RTX_TRACE_SHADE(128, rtx::kLdsBvh2, lds_fused);
       else
-        rtx::k_trace_shade<256, rtx::kLdsBvh2><<<dim3(div_up(seg_max_upper, 256), nseg), 256, lds_fused, st>>>(
-            c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp, sum);
+        RTX_TRACE_SHADE(256, rtx::kLdsBvh2, lds_fused);
+#undef RTX_TRACE_SHADE
       lt.end();
       launches++;
     } else {
