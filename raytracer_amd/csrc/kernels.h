@@ -59,6 +59,8 @@ struct SceneDev {
                          // a hit, computed once on the host with the float operations hit_surface would use
   const float4* mat0;    // per material: (albedo.rgb, emission)
   const int* mat1;       //               surface
+  const float4* tri_mat; // small scenes only (else null): the material copied out per triangle slot, (albedo.rgb,
+  const int* tri_surf;   // emission) and surface, so that a hit's loads do not wait for its material index
   // Analytic objects, in the order spheres, boxes, planes; object i of that
   // combined list has material (sph1[i], sph2[i]).
   const float4* sph0;    // per sphere: (c.xyz, r)
@@ -866,6 +868,47 @@ __device__ __forceinline__ bool occluded(const SceneDev& sc, const Geom& g, f3 o
 __device__ __forceinline__ void hit_surface(const SceneDev& sc, const Geom& g, uint32_t id, f3 o, f3 d, float t,
                                             f3& n, f3& albedo, float& emission, int& surface,
                                             LastSphere* last = nullptr) {
+  if (sc.tri_mat != nullptr && last == nullptr) {
+    // Small scenes: everything a hit may need is requested before anything is used, from addresses that are valid
+    // for every lane (a lane that hit a sphere reads triangle slot 0 for nothing and the other way round; a few
+    // cached lines), so a wave whose lanes hit spheres and triangles waits for one round trip.  With the loads
+    // inside the branches it waits for the sphere's, then for the triangle's normal and material index, then for
+    // the material that index names.
+    const bool analytic = (id & kSphereBit) != 0;
+    const uint32_t nobj = sc.num_spheres + sc.num_boxes + sc.num_planes;
+    const uint32_t i = analytic ? (id & ~kSphereBit) : 0u, slot = analytic ? 0u : id;
+    float4 ma = make_float4(0, 0, 0, 0), sp = make_float4(0, 0, 0, 1), N = ma, mt = ma;
+    int surf_a = 0, surf_t = 0;
+    if (nobj != 0) {
+      ma = sc.sph1[i];
+      surf_a = sc.sph2[i];
+    }
+    if (sc.num_spheres != 0) sp = sc.sph0[i < sc.num_spheres ? i : 0u];
+    if (sc.num_tris != 0) {
+      N = sc.tri_nrm[slot];
+      mt = sc.tri_mat[slot];
+      surf_t = sc.tri_surf[slot];
+    }
+    if (analytic) {
+      const f3 p = vadd(o, vscale(d, t));
+      if (i < sc.num_spheres) {
+        n = vdivs(vsub(p, mk3(sp.x, sp.y, sp.z)), sp.w);
+      } else if (i < sc.num_spheres + sc.num_boxes) {
+        float4 a = sc.box0[i - sc.num_spheres], b = sc.box1[i - sc.num_spheres];
+        n = box_normal(mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), p);
+      } else {
+        float4 b = sc.pln1[i - sc.num_spheres - sc.num_boxes];
+        n = mk3(b.x, b.y, b.z);
+      }
+    } else {
+      n = mk3(N.x, N.y, N.z);  // = vnormalized(Ng), bit for bit (see rtx_set_scene)
+    }
+    const float4 m = analytic ? ma : mt;
+    albedo = mk3(m.x, m.y, m.z);
+    emission = m.w;
+    surface = analytic ? surf_a : surf_t;
+    return;
+  }
   if (id & kSphereBit) {
     uint32_t i = id & ~kSphereBit;
     f3 p = vadd(o, vscale(d, t));

@@ -199,8 +199,8 @@ struct rtx_ctx {
 
   // scene
   bool have_scene = false;
-  DevBuf<float4> nodes, tris, tri_nrm, mat0, sph0, sph1, box0, box1, pln0, pln1, light0, light1, light2, light3;
-  DevBuf<int> mat1, sph2, sph3;
+  DevBuf<float4> nodes, tris, tri_nrm, tri_mat, mat0, sph0, sph1, box0, box1, pln0, pln1, light0, light1, light2, light3;
+  DevBuf<int> mat1, tri_surf, sph2, sph3;
   rtx::SceneDev scene{};
   rtx_scene_info info{};
   int stack_entries = 8;    // stack entries per lane kept in LDS
@@ -309,7 +309,7 @@ void free_ctx(rtx_ctx* c) {
     if (Rccl* r = rccl()) (void)r->CommDestroy(c->comm);
     c->comm = nullptr;
   }
-  c->nodes.release(); c->tris.release(); c->tri_nrm.release();
+  c->nodes.release(); c->tris.release(); c->tri_nrm.release(); c->tri_mat.release(); c->tri_surf.release();
   c->mat0.release(); c->mat1.release(); c->sph0.release(); c->sph1.release(); c->sph2.release(); c->sph3.release();
   c->box0.release(); c->box1.release(); c->pln0.release(); c->pln1.release();
   c->light0.release(); c->light1.release(); c->light2.release(); c->light3.release();
@@ -615,6 +615,22 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
   HIP_TRY(c->tri_nrm.upload(tn));
   HIP_TRY(c->mat0.upload(m0));
   HIP_TRY(c->mat1.upload(m1));
+  // Small scenes (everything but the wide tree): the material copied out per triangle slot, so that the loads of
+  // a hit do not wait for its material index (hit_surface).  Large meshes keep the one table: their shading is
+  // bound by memory traffic, and a table of a few materials stays in cache where a per-slot copy would not.
+  std::vector<float4> tm;
+  std::vector<int> ts;
+  if (bvh.width != 4) {
+    tm.resize(nt);
+    ts.resize(nt);
+    for (size_t slot = 0; slot < nt; slot++) {
+      const uint32_t mi = s->material_index[bvh.order[slot]];
+      tm[slot] = m0[mi];
+      ts[slot] = m1[mi];
+    }
+  }
+  HIP_TRY(c->tri_mat.upload(tm));
+  HIP_TRY(c->tri_surf.upload(ts));
   HIP_TRY(c->sph0.upload(sp0));
   HIP_TRY(c->sph1.upload(sp1));
   HIP_TRY(c->sph2.upload(sp2));
@@ -631,6 +647,8 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
   rtx::SceneDev& d = c->scene;
   d.nodes = c->nodes.p; d.tris = c->tris.p; d.tri_nrm = c->tri_nrm.p;
   d.mat0 = c->mat0.p; d.mat1 = c->mat1.p;
+  d.tri_mat = tm.empty() ? nullptr : c->tri_mat.p;
+  d.tri_surf = tm.empty() ? nullptr : c->tri_surf.p;
   d.sph0 = c->sph0.p; d.sph1 = c->sph1.p; d.sph2 = c->sph2.p; d.sph3 = c->sph3.p;
   d.box0 = c->box0.p; d.box1 = c->box1.p; d.pln0 = c->pln0.p; d.pln1 = c->pln1.p;
   d.num_boxes = (uint32_t)s->num_boxes;
