@@ -61,6 +61,7 @@ struct SceneDev {
   const int* mat1;       //               surface
   const float4* tri_mat; // small scenes only (else null): the material copied out per triangle slot, (albedo.rgb,
   const int* tri_surf;   // emission) and surface, so that a hit's loads do not wait for its material index
+  int few_surfaces;      // 1: a handful of spheres and triangles and nothing else (hit_surface reads them all)
   // Analytic objects, in the order spheres, boxes, planes; object i of that
   // combined list has material (sph1[i], sph2[i]).
   const float4* sph0;    // per sphere: (c.xyz, r)
@@ -868,6 +869,37 @@ __device__ __forceinline__ bool occluded(const SceneDev& sc, const Geom& g, f3 o
 __device__ __forceinline__ void hit_surface(const SceneDev& sc, const Geom& g, uint32_t id, f3 o, f3 d, float t,
                                             f3& n, f3& albedo, float& emission, int& surface,
                                             LastSphere* last = nullptr) {
+  if (sc.few_surfaces && last == nullptr) {
+    // A handful of surfaces: every lane reads all of them, which makes the reads scalar loads (tens of cycles
+    // from the scalar cache, three per surface, requested together), and keeps the one it hit.  The per-lane
+    // lookup below costs a round trip through the vector memory path, some 1 500 cycles of a wave that lives 12 000.
+    float4 c = make_float4(0, 0, 0, 1), m = make_float4(0, 0, 0, 0);
+    f3 nt = mk3(0, 0, 0);
+    int sf = 0;
+    for (uint32_t i = 0; i < sc.num_spheres; i++) {
+      const float4 ci = sc.sph0[i], mi = sc.sph1[i];
+      const int si = sc.sph2[i];
+      if (id == (kSphereBit | i)) {
+        c = ci;
+        m = mi;
+        sf = si;
+      }
+    }
+    for (uint32_t k = 0; k < sc.num_tris; k++) {
+      const float4 Nk = sc.tri_nrm[k], mk = sc.tri_mat[k];
+      const int sk = sc.tri_surf[k];
+      if (id == k) {
+        nt = mk3(Nk.x, Nk.y, Nk.z);
+        m = mk;
+        sf = sk;
+      }
+    }
+    n = (id & kSphereBit) ? vdivs(vsub(vadd(o, vscale(d, t)), mk3(c.x, c.y, c.z)), c.w) : nt;
+    albedo = mk3(m.x, m.y, m.z);
+    emission = m.w;
+    surface = sf;
+    return;
+  }
   if (sc.tri_mat != nullptr && last == nullptr) {
     // Small scenes: everything a hit may need is requested before anything is used, from addresses that are valid
     // for every lane (a lane that hit a sphere reads triangle slot 0 for nothing and the other way round; a few

@@ -682,6 +682,8 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
     c->trace_mode = rtx::kLdsBvh2;  // (a very deep small tree leaves the LDS to the stacks and stays in global memory)
   else
     c->trace_mode = rtx::kGlobalBvh2;
+  // (a handful of surfaces and nothing else: hit_surface reads them all through the scalar cache)
+  d.few_surfaces = c->trace_mode == rtx::kFewTriangles && s->num_spheres <= 4 && s->num_boxes == 0 && s->num_planes == 0;
   c->have_scene = true;
   if (c->twin) {
     mirror_scene(c);
