@@ -62,6 +62,9 @@ struct SceneDev {
   const float4* tri_mat; // small scenes only (else null): the material copied out per triangle slot, (albedo.rgb,
   const int* tri_surf;   // emission) and surface, so that a hit's loads do not wait for its material index
   int few_surfaces;      // 1: a handful of spheres and triangles and nothing else (hit_surface reads them all)
+  const float4* leaf_box;  // trees of up to kLeafTaskMaxLeaves leaves (else null): per leaf (lo.x, hi.x, lo.y, hi.y),
+  uint32_t num_leaf_boxes; //   (lo.z, hi.z, leaf word bits, 0): the leaves' boxes as the two-child nodes hold them
+  uint32_t leaf_task_cap;  // (ray, leaf) pairs the block's queue holds per thread (block_closest_by_leaf_tasks)
   // Analytic objects, in the order spheres, boxes, planes; object i of that
   // combined list has material (sph1[i], sph2[i]).
   const float4* sph0;    // per sphere: (c.xyz, r)
@@ -172,7 +175,9 @@ enum TraceMode {
   kLdsBvh2 = 1,     // two-child nodes and triangles staged in LDS (small scenes)
   kGlobalBvh4 = 2,  // four-child quantised nodes in global memory (large scenes)
   kFewTriangles = 3,  // no tree: every ray tests every triangle (meshes of up to kFewTrianglesMax)
+  kLdsLeafTasks = 4,  // bounce kernel of trees of up to kLeafTaskMaxLeaves leaves: block_closest_by_leaf_tasks
 };
+constexpr uint32_t kLeafTaskMaxLeaves = 32;
 // A mesh this small (the ground quad of the reference's sphere scenes) is tested like the analytic
 // objects: all lanes read the same records, which the compiler turns into scalar loads; no tree,
 // no stack, and no copy of the scene into LDS with the barrier behind it.
@@ -1781,20 +1786,133 @@ __global__ __launch_bounds__(256) void k_shade_wave_append(SceneDev sc, Queue in
   }
 }
 
+// Closest mesh hit for the rays of a whole block when the tree has a handful of leaves (Cornell's seventeen).
+// In a walk a ray needs about eight node and 1.2 leaf visits, but its wave runs twenty node rounds and seven
+// leaf rounds, the latter with a sixth of the lanes at work, because the lanes' walks differ.  Here every lane
+// tests the boxes of all leaves (scalar operands, no stack, no divergence; what an ordered walk would have
+// culled behind a hit is a twentieth of the leaf visits in such a scene), the (ray, leaf) pairs go to a queue
+// in LDS, and the block's waves test them in dense batches of 64; a hit is merged into its ray's record with a
+// 64-bit minimum of (t, primitive id, slot): the smallest t and, among equal t, the lowest primitive id, which is
+// the rule of Mesh::intersect (reference Obj.h:184-195).  Every thread of the block calls this (barriers);
+// `active` lanes bring a ray, and get the closest hit with t <= t_limit (best_slot kMiss, best_t = t_limit:
+// none).  The queue holds sc.leaf_task_cap pairs per thread on average (a ray meets 1.3 leaf boxes); a lane whose
+// pairs do not fit tests its leaves itself.  LDS at `ws`: leaf_task_lds_bytes; the caller has set ws[0] to
+// (0, queue capacity, ...) as uint32 before its last barrier.
+struct LeafTaskHead {
+  uint32_t count, valid_end, pad0, pad1;  // pairs reserved so far; pairs [0, valid_end) are written
+};
+__host__ __device__ constexpr size_t leaf_task_lds_bytes(uint32_t block, uint32_t cap_per_thread) {
+  return sizeof(LeafTaskHead) + 4 * kLeafTaskMaxLeaves + (size_t)block * (32 + 8 + 2 * cap_per_thread);
+}
+template <int BLOCK>
+__device__ __forceinline__ void leaf_task_begin(const SceneDev& sc, float4* ws) {
+  LeafTaskHead* const head = reinterpret_cast<LeafTaskHead*>(ws);
+  uint32_t* const leaf_word = reinterpret_cast<uint32_t*>(ws + 1);
+  if (threadIdx.x == 0) {
+    head->count = 0;
+    head->valid_end = sc.leaf_task_cap * BLOCK;
+  }
+  if (threadIdx.x < sc.num_leaf_boxes) leaf_word[threadIdx.x] = __float_as_uint(sc.leaf_box[2 * threadIdx.x + 1].z);
+}
+template <int BLOCK>
+__device__ __forceinline__ void block_closest_by_leaf_tasks(const SceneDev& sc, const Geom& g, float4* ws, bool active,
+                                                            f3 o, f3 d, float t_limit, float& best_t,
+                                                            uint32_t& best_slot) {
+  LeafTaskHead* const head = reinterpret_cast<LeafTaskHead*>(ws);
+  uint32_t* const leaf_word = reinterpret_cast<uint32_t*>(ws + 1);
+  float4* const ray_o = ws + 1 + kLeafTaskMaxLeaves / 4;
+  float4* const ray_d = ray_o + BLOCK;
+  unsigned long long* const best = reinterpret_cast<unsigned long long*>(ray_d + BLOCK);
+  uint16_t* const tasks = reinterpret_cast<uint16_t*>(best + BLOCK);
+  const uint32_t tid = threadIdx.x, cap = sc.leaf_task_cap * BLOCK;
+  uint32_t own = 0;  // leaves this lane tests itself (its pairs did not fit)
+  if (active) {
+    Walk w;
+    walk_begin<kLdsBvh2>(sc, o, d, w);
+    uint32_t mask = 0;
+    for (uint32_t l = 0; l < sc.num_leaf_boxes; l++) {
+      const float4 a = sc.leaf_box[2 * l], b = sc.leaf_box[2 * l + 1];
+      float tn;
+      if (slab(a.x, a.y, a.z, a.w, b.x, b.y, w.inv, w.add_lo, w.add_hi, w.tmin, t_limit, tn)) mask |= 1u << l;
+    }
+    ray_o[tid] = make_float4(o.x, o.y, o.z, 0.0f);
+    ray_d[tid] = make_float4(d.x, d.y, d.z, 0.0f);
+    best[tid] = ((unsigned long long)__float_as_uint(t_limit) << 32) | 0xffffffffull;  // any hit at t_limit wins over none
+    if (mask != 0) {
+      const uint32_t cnt = (uint32_t)__popc(mask);
+      uint32_t at = atomicAdd(&head->count, cnt);
+      if (at + cnt <= cap) {
+        while (mask != 0) {
+          const uint32_t l = (uint32_t)__builtin_ctz(mask);
+          mask &= mask - 1u;
+          tasks[at++] = (uint16_t)((tid << 5) | l);
+        }
+      } else {
+        // (every reservation after this one starts beyond the capacity as well, so the written pairs are the
+        // ones below the lowest start of a lane that did not fit)
+        atomicMin(&head->valid_end, at);
+        own = mask;
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t ntasks = min(head->count, head->valid_end);
+  for (uint32_t k = tid; k < ntasks; k += BLOCK) {
+    const uint32_t task = tasks[k], r = task >> 5;
+    const float4 O = ray_o[r], D = ray_d[r];
+    float t = INFINITY;
+    uint32_t prim = kMiss, slot = kMiss;
+    leaf_closest<kLdsBvh2>(g, leaf_word[task & 31u], mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), sc.eps, t, prim, slot);
+    if (slot != kMiss)
+      atomicMin(&best[r], ((unsigned long long)__float_as_uint(t) << 32) | ((unsigned long long)prim << 16) | slot);
+  }
+  while (own != 0) {
+    const uint32_t l = (uint32_t)__builtin_ctz(own);
+    own &= own - 1u;
+    float t = INFINITY;
+    uint32_t prim = kMiss, slot = kMiss;
+    leaf_closest<kLdsBvh2>(g, leaf_word[l], o, d, sc.eps, t, prim, slot);
+    if (slot != kMiss)
+      atomicMin(&best[tid], ((unsigned long long)__float_as_uint(t) << 32) | ((unsigned long long)prim << 16) | slot);
+  }
+  __syncthreads();
+  best_t = t_limit;
+  best_slot = kMiss;
+  if (active) {
+    const unsigned long long key = best[tid];
+    best_t = __uint_as_float((uint32_t)(key >> 32));
+    best_slot = (uint32_t)key == 0xffffffffu ? kMiss : ((uint32_t)key & 0xffffu);
+  }
+}
+
 // k_intersect and k_shade_wave_append in one launch, for scenes whose closest-hit search is
 // a handful of tests (tree staged in LDS, a few nodes): the search then costs less than
 // carrying the ray to a kernel of its own and the hit back, so each path is read once per
 // bounce and the hit stays in registers.
 // (eight waves per SIMD: the compiler then keeps to 96 scalar registers as well, which it passed by five
 // otherwise, and a wave of this kernel mostly waits: sample2 8.8 -> 8.3 ms, Cornell's bounces 51.7 -> 49.4)
+// (kLdsLeafTasks: its LDS workspace leaves room for seven blocks of 256 per CU, so seven waves per SIMD it is)
 template <int BLOCK, int MODE, bool LIGHTS>
-__global__ __launch_bounds__(BLOCK, 8) void k_trace_shade(SceneDev sc, Queue in, Queue out, ShadowQueue sq,
+__global__ __launch_bounds__(BLOCK, MODE == kLdsLeafTasks ? 7 : 8) void k_trace_shade(SceneDev sc, Queue in, Queue out, ShadowQueue sq,
                                                        SegCounter* seg, int qi, uint32_t cap, float* res,
                                                        TraceParams tp, const Primary* __restrict__ prp, Summary* sum) {
   const uint32_t s = blockIdx.y;
   const uint32_t n = seg_paths(seg[s].c[qi]);
   if (blockIdx.x * BLOCK >= n) return;  // whole blocks beyond the fill leave; the rest stay for the barrier and the ballots
-  RTX_TRACE_PROLOGUE();
+  constexpr int WALK = MODE == kLdsLeafTasks ? kLdsBvh2 : MODE;   // (how a lane of this kernel would walk the tree)
+  extern __shared__ float4 lds_dyn[];
+  Stack stk;
+  stk.lds = (lds_int_ptr)(reinterpret_cast<int*>(lds_dyn) + threadIdx.x);
+  stk.stride = BLOCK;
+  stk.lds_entries = tp.lds_entries;
+  stk.all_in_lds = true;
+  stk.spill_stride = tp.spill_stride;
+  stk.spill = (global_int_ptr)(tp.spill + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * BLOCK + threadIdx.x));
+  // LDS: [per-lane stacks | scene] for the walks, [scene | leaf-task workspace] for kLdsLeafTasks
+  const uint32_t scene_at = MODE == kLdsLeafTasks ? 0u : (tp.lds_entries * BLOCK) / 4;
+  float4* const task_ws = lds_dyn + kLdsRecordStride * (sc.num_nodes + sc.num_tris);
+  if constexpr (MODE == kLdsLeafTasks) leaf_task_begin<BLOCK>(sc, task_ws);  // (ahead of the staging's barrier)
+  const Geom geom = WALK == kLdsBvh2 ? stage_geom_lds(sc, lds_dyn + scene_at, threadIdx.x, BLOCK) : global_geom(sc);
   const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
   const bool active = j < n;
   const uint32_t i = s * cap + j;
@@ -1803,15 +1921,30 @@ __global__ __launch_bounds__(BLOCK, 8) void k_trace_shade(SceneDev sc, Queue in,
   ShadowReq sr;
   SurfaceHit sh;
   bool alive = false, want_shadow = false, did_nee = false, bad = false;
+  float t = INFINITY;
+  uint32_t id = kMiss;
+  if constexpr (MODE == kLdsLeafTasks) {
+    // cast_ray with the mesh part done by the whole block
+    p.o = p.d = mk3(0.0f, 0.0f, 0.0f);
+    float ts = INFINITY;
+    uint32_t sid = kMiss;
+    if (active) {
+      load_path(sc, in, i, j >= seg[s].gen_slot0, *prp, (uint32_t)seg[s].gen_ordinal0 + (j - seg[s].gen_slot0), p);
+      analytic_closest(sc, p.o, p.d, ts, sid);
+    }
+    uint32_t slot;
+    block_closest_by_leaf_tasks<BLOCK>(sc, geom, task_ws, active, p.o, p.d, ts, t, slot);
+    id = slot != kMiss ? slot : sid;
+  }
   // Without lights a bounce queues no light sample, so the append counts paths only, and which paths go on is
   // known once the roulette is through: the slots are reserved there and the atomic's round trip runs beside
   // the sampling of the next direction.
   constexpr bool reserve_early = !LIGHTS;  // (LIGHTS: the scene has any, sc.num_lights != 0)
   if (active) {
-    load_path(sc, in, i, j >= seg[s].gen_slot0, *prp, (uint32_t)seg[s].gen_ordinal0 + (j - seg[s].gen_slot0), p);
-    float t;
-    uint32_t id;
-    cast_ray<MODE>(sc, geom, p.o, p.d, stk, t, id);
+    if constexpr (MODE != kLdsLeafTasks) {
+      load_path(sc, in, i, j >= seg[s].gen_slot0, *prp, (uint32_t)seg[s].gen_ordinal0 + (j - seg[s].gen_slot0), p);
+      cast_ray<WALK>(sc, geom, p.o, p.d, stk, t, id);
+    }
     alive = reserve_early ? shade_arrive<true>(sc, global_geom(sc), p, t, id, sh)
                           : shade_bounce(sc, global_geom(sc), p, t, id, want_shadow, did_nee, sr);
     if (!alive) {

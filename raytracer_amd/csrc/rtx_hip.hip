@@ -199,7 +199,7 @@ struct rtx_ctx {
 
   // scene
   bool have_scene = false;
-  DevBuf<float4> nodes, tris, tri_nrm, tri_mat, mat0, sph0, sph1, box0, box1, pln0, pln1, light0, light1, light2, light3;
+  DevBuf<float4> nodes, tris, tri_nrm, tri_mat, leaf_box, mat0, sph0, sph1, box0, box1, pln0, pln1, light0, light1, light2, light3;
   DevBuf<int> mat1, tri_surf, sph2, sph3;
   rtx::SceneDev scene{};
   rtx_scene_info info{};
@@ -309,7 +309,7 @@ void free_ctx(rtx_ctx* c) {
     if (Rccl* r = rccl()) (void)r->CommDestroy(c->comm);
     c->comm = nullptr;
   }
-  c->nodes.release(); c->tris.release(); c->tri_nrm.release(); c->tri_mat.release(); c->tri_surf.release();
+  c->nodes.release(); c->tris.release(); c->tri_nrm.release(); c->tri_mat.release(); c->tri_surf.release(); c->leaf_box.release();
   c->mat0.release(); c->mat1.release(); c->sph0.release(); c->sph1.release(); c->sph2.release(); c->sph3.release();
   c->box0.release(); c->box1.release(); c->pln0.release(); c->pln1.release();
   c->light0.release(); c->light1.release(); c->light2.release(); c->light3.release();
@@ -631,6 +631,33 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
   }
   HIP_TRY(c->tri_mat.upload(tm));
   HIP_TRY(c->tri_surf.upload(ts));
+  // Trees of a handful of leaves: the leaves' boxes as a list, for the bounce kernel that tests them all and hands
+  // the triangle tests out as tasks of its block (block_closest_by_leaf_tasks).  16-bit primitive ids and slots there.
+  std::vector<float4> lb;
+  if (bvh.width == 2 && nt < 65536) {
+    for (size_t k = 0; k + 3 < nodes.size() && lb.size() <= 2 * rtx::kLeafTaskMaxLeaves; k += 4) {
+      const float4 &q0 = nodes[k], &q1 = nodes[k + 1], &q2 = nodes[k + 2], &q3 = nodes[k + 3];
+      int c0, c1;
+      std::memcpy(&c0, &q3.x, 4);
+      std::memcpy(&c1, &q3.y, 4);
+      if (c0 < 0 && c0 != rtx::kTraversalDone) {
+        float w;
+        const uint32_t leaf = ~(uint32_t)c0;
+        std::memcpy(&w, &leaf, 4);
+        lb.push_back(make_float4(q0.x, q0.y, q0.z, q0.w));
+        lb.push_back(make_float4(q2.x, q2.y, w, 0.f));
+      }
+      if (c1 < 0 && c1 != rtx::kTraversalDone) {
+        float w;
+        const uint32_t leaf = ~(uint32_t)c1;
+        std::memcpy(&w, &leaf, 4);
+        lb.push_back(make_float4(q1.x, q1.y, q1.z, q1.w));
+        lb.push_back(make_float4(q2.z, q2.w, w, 0.f));
+      }
+    }
+    if (lb.size() > 2 * rtx::kLeafTaskMaxLeaves || std::getenv("RTX_NO_LEAF_TASKS")) lb.clear();  // (the latter: test hook)
+  }
+  HIP_TRY(c->leaf_box.upload(lb));
   HIP_TRY(c->sph0.upload(sp0));
   HIP_TRY(c->sph1.upload(sp1));
   HIP_TRY(c->sph2.upload(sp2));
@@ -649,6 +676,10 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
   d.mat0 = c->mat0.p; d.mat1 = c->mat1.p;
   d.tri_mat = tm.empty() ? nullptr : c->tri_mat.p;
   d.tri_surf = tm.empty() ? nullptr : c->tri_surf.p;
+  d.leaf_box = lb.empty() ? nullptr : c->leaf_box.p;
+  d.num_leaf_boxes = (uint32_t)lb.size() / 2;
+  d.leaf_task_cap = 8;
+  if (const char* e = std::getenv("RTX_LEAF_TASK_CAP")) d.leaf_task_cap = (uint32_t)std::min(32, std::max(1, std::atoi(e)));  // (test hook: 1 makes lanes fall back)
   d.sph0 = c->sph0.p; d.sph1 = c->sph1.p; d.sph2 = c->sph2.p; d.sph3 = c->sph3.p;
   d.box0 = c->box0.p; d.box1 = c->box1.p; d.pln0 = c->pln0.p; d.pln1 = c->pln1.p;
   d.num_boxes = (uint32_t)s->num_boxes;
@@ -951,6 +982,8 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
   } while (0)
       if (few)
         RTX_TRACE_SHADE(128, rtx::kFewTriangles, 0);
+      else if (c->scene.num_leaf_boxes != 0)   // a handful of leaves: their triangle tests as tasks of the block
+        RTX_TRACE_SHADE(256, rtx::kLdsLeafTasks, scene_lds + rtx::leaf_task_lds_bytes(256, c->scene.leaf_task_cap));
       else if (fused_block == 128)
         RTX_TRACE_SHADE(128, rtx::kLdsBvh2, lds_fused);
       else
