@@ -1885,6 +1885,64 @@ __device__ __forceinline__ void block_closest_by_leaf_tasks(const SceneDev& sc, 
   }
 }
 
+// The same for occlusion: is any triangle of the mesh hit with eps < t < tfar (mesh_any)?  A pair that finds a
+// hit sets its ray's flag; the other pairs of that ray are tested all the same (a walk would have stopped), which
+// costs little where most segments are free.  The caller has run leaf_task_begin and a barrier since the last call.
+template <int BLOCK>
+__device__ __forceinline__ bool block_any_by_leaf_tasks(const SceneDev& sc, const Geom& g, float4* ws, bool active,
+                                                        f3 o, f3 d, float tfar) {
+  LeafTaskHead* const head = reinterpret_cast<LeafTaskHead*>(ws);
+  uint32_t* const leaf_word = reinterpret_cast<uint32_t*>(ws + 1);
+  float4* const ray_o = ws + 1 + kLeafTaskMaxLeaves / 4;
+  float4* const ray_d = ray_o + BLOCK;
+  uint32_t* const flag = reinterpret_cast<uint32_t*>(ray_d + BLOCK);
+  uint16_t* const tasks = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned long long*>(ray_d + BLOCK) + BLOCK);
+  const uint32_t tid = threadIdx.x, cap = sc.leaf_task_cap * BLOCK;
+  uint32_t own = 0;
+  if (active) {
+    Walk w;
+    walk_begin<kLdsBvh2>(sc, o, d, w);
+    uint32_t mask = 0;
+    for (uint32_t l = 0; l < sc.num_leaf_boxes; l++) {
+      const float4 a = sc.leaf_box[2 * l], b = sc.leaf_box[2 * l + 1];
+      float tn;
+      if (slab(a.x, a.y, a.z, a.w, b.x, b.y, w.inv, w.add_lo, w.add_hi, w.tmin, tfar, tn)) mask |= 1u << l;
+    }
+    ray_o[tid] = make_float4(o.x, o.y, o.z, tfar);
+    ray_d[tid] = make_float4(d.x, d.y, d.z, 0.0f);
+    flag[tid] = 0;
+    if (mask != 0) {
+      const uint32_t cnt = (uint32_t)__popc(mask);
+      uint32_t at = atomicAdd(&head->count, cnt);
+      if (at + cnt <= cap) {
+        while (mask != 0) {
+          const uint32_t l = (uint32_t)__builtin_ctz(mask);
+          mask &= mask - 1u;
+          tasks[at++] = (uint16_t)((tid << 5) | l);
+        }
+      } else {
+        atomicMin(&head->valid_end, at);
+        own = mask;
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t ntasks = min(head->count, head->valid_end);
+  for (uint32_t k = tid; k < ntasks; k += BLOCK) {
+    const uint32_t task = tasks[k], r = task >> 5;
+    const float4 O = ray_o[r], D = ray_d[r];
+    if (leaf_any<kLdsBvh2>(g, leaf_word[task & 31u], mk3(O.x, O.y, O.z), mk3(D.x, D.y, D.z), sc.eps, O.w)) flag[r] = 1;
+  }
+  bool hit = false;
+  while (own != 0 && !hit) {
+    const uint32_t l = (uint32_t)__builtin_ctz(own);
+    own &= own - 1u;
+    hit = leaf_any<kLdsBvh2>(g, leaf_word[l], o, d, sc.eps, tfar);
+  }
+  __syncthreads();
+  return active && (hit || flag[tid] != 0);
+}
+
 // k_intersect and k_shade_wave_append in one launch, for scenes whose closest-hit search is
 // a handful of tests (tree staged in LDS, a few nodes): the search then costs less than
 // carrying the ray to a kernel of its own and the hit back, so each path is read once per
@@ -1925,6 +1983,7 @@ __global__ __launch_bounds__(BLOCK, MODE == kLdsLeafTasks ? 7 : 8) void k_trace_
   uint32_t id = kMiss;
   if constexpr (MODE == kLdsLeafTasks) {
     // cast_ray with the mesh part done by the whole block
+    // (requesting the path ahead of the staging, as k_shadow_leaf_tasks does with its samples, measured slower here)
     p.o = p.d = mk3(0.0f, 0.0f, 0.0f);
     float ts = INFINITY;
     uint32_t sid = kMiss;
@@ -2037,6 +2096,32 @@ __global__ __launch_bounds__(BLOCK, 8) void k_shadow(SceneDev sc, Queue paths, S
     bool occ = occluded<MODE>(sc, geom, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), a.w, stk);
     if (!occ) add_contribution(paths, sq, k, __float_as_uint(b.w));
   }
+}
+
+// k_shadow for trees of a handful of leaves (block_any_by_leaf_tasks), one batch of light samples per block.
+// Dynamic LDS: [scene | leaf-task workspace].
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK, 7) void k_shadow_leaf_tasks(SceneDev sc, Queue paths, ShadowQueue sq,
+                                                             const SegCounter* seg, int q_out, uint32_t cap) {
+  const uint32_t s = blockIdx.y;
+  const uint32_t n = seg_shadow(seg[s].c[q_out]);
+  if (blockIdx.x * BLOCK >= n) return;
+  extern __shared__ float4 lds_dyn[];
+  float4* const task_ws = lds_dyn + kLdsRecordStride * (sc.num_nodes + sc.num_tris);
+  const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
+  const bool active = j < n;
+  const uint32_t k = s * cap + (active ? j : 0u);
+  float4 a = make_float4(0, 0, 0, 0), b = a;
+  if (active) {  // (requested ahead of the staging, whose copy and barrier then run beside the round trip)
+    a = sq.q0[k];
+    b = sq.q1[k];
+  }
+  leaf_task_begin<BLOCK>(sc, task_ws);
+  const Geom geom = stage_geom_lds(sc, lds_dyn, threadIdx.x, BLOCK);  // (ends with a barrier)
+  const bool free_so_far = active && !analytic_any(sc, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), a.w);
+  const bool occ = block_any_by_leaf_tasks<BLOCK>(sc, geom, task_ws, free_so_far, mk3(a.x, a.y, a.z),
+                                                  mk3(b.x, b.y, b.z), a.w);
+  if (free_so_far && !occ) add_contribution(paths, sq, k, __float_as_uint(b.w));
 }
 
 // k_shadow for the wide tree in global memory, with the lanes of a wave kept supplied as in

@@ -1021,6 +1021,10 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
         const uint32_t gxw = std::max(1u, std::min(per_seg, div_up(seg_max_upper, kTraceBlock)));
         rtx::k_shadow_wide<kTraceBlock><<<dim3(gxw, nseg), kTraceBlock, lds, st>>>(c->scene, qn, sq, seg, nxt, cap, tp,
                                                                                    c->shadow_refill_lanes);
+      } else if (c->scene.num_leaf_boxes != 0 && fused) {
+        rtx::k_shadow_leaf_tasks<256><<<dim3(gx256, nseg), 256,
+                                        scene_lds + rtx::leaf_task_lds_bytes(256, c->scene.leaf_task_cap), st>>>(
+            c->scene, qn, sq, seg, nxt, cap);
       } else {
         RTX_BY_MODE(c->trace_mode, rtx::k_shadow, kTraceBlock, (dim3(gx128, nseg), kTraceBlock, lds, st),
                     (c->scene, qn, sq, seg, nxt, cap, tp));
