@@ -1804,6 +1804,22 @@ struct LeafTaskHead {
 __host__ __device__ constexpr size_t leaf_task_lds_bytes(uint32_t block, uint32_t cap_per_thread) {
   return sizeof(LeafTaskHead) + 4 * kLeafTaskMaxLeaves + (size_t)block * (32 + 8 + 2 * cap_per_thread);
 }
+// Bit l set: the ray of walk `w` meets the box of leaf l between w.tmin and tmax.  The boxes come through the
+// scalar cache; each is requested one test ahead, so that a test does not begin with a wait for its operands.
+__device__ __forceinline__ uint32_t leaf_boxes_met(const SceneDev& sc, const Walk& w, float tmax) {
+  uint32_t mask = 0;
+  const uint32_t nl = sc.num_leaf_boxes;
+  float4 a = sc.leaf_box[0], b = sc.leaf_box[1];
+  for (uint32_t l = 0; l < nl; l++) {
+    const uint32_t nx = l + 1u < nl ? l + 1u : l;
+    const float4 na = sc.leaf_box[2 * nx], nb = sc.leaf_box[2 * nx + 1];
+    float tn;
+    if (slab(a.x, a.y, a.z, a.w, b.x, b.y, w.inv, w.add_lo, w.add_hi, w.tmin, tmax, tn)) mask |= 1u << l;
+    a = na;
+    b = nb;
+  }
+  return mask;
+}
 template <int BLOCK>
 __device__ __forceinline__ void leaf_task_begin(const SceneDev& sc, float4* ws) {
   LeafTaskHead* const head = reinterpret_cast<LeafTaskHead*>(ws);
@@ -1829,12 +1845,7 @@ __device__ __forceinline__ void block_closest_by_leaf_tasks(const SceneDev& sc, 
   if (active) {
     Walk w;
     walk_begin<kLdsBvh2>(sc, o, d, w);
-    uint32_t mask = 0;
-    for (uint32_t l = 0; l < sc.num_leaf_boxes; l++) {
-      const float4 a = sc.leaf_box[2 * l], b = sc.leaf_box[2 * l + 1];
-      float tn;
-      if (slab(a.x, a.y, a.z, a.w, b.x, b.y, w.inv, w.add_lo, w.add_hi, w.tmin, t_limit, tn)) mask |= 1u << l;
-    }
+    uint32_t mask = leaf_boxes_met(sc, w, t_limit);
     ray_o[tid] = make_float4(o.x, o.y, o.z, 0.0f);
     ray_d[tid] = make_float4(d.x, d.y, d.z, 0.0f);
     best[tid] = ((unsigned long long)__float_as_uint(t_limit) << 32) | 0xffffffffull;  // any hit at t_limit wins over none
@@ -1902,12 +1913,7 @@ __device__ __forceinline__ bool block_any_by_leaf_tasks(const SceneDev& sc, cons
   if (active) {
     Walk w;
     walk_begin<kLdsBvh2>(sc, o, d, w);
-    uint32_t mask = 0;
-    for (uint32_t l = 0; l < sc.num_leaf_boxes; l++) {
-      const float4 a = sc.leaf_box[2 * l], b = sc.leaf_box[2 * l + 1];
-      float tn;
-      if (slab(a.x, a.y, a.z, a.w, b.x, b.y, w.inv, w.add_lo, w.add_hi, w.tmin, tfar, tn)) mask |= 1u << l;
-    }
+    uint32_t mask = leaf_boxes_met(sc, w, tfar);
     ray_o[tid] = make_float4(o.x, o.y, o.z, tfar);
     ray_d[tid] = make_float4(d.x, d.y, d.z, 0.0f);
     flag[tid] = 0;
