@@ -170,6 +170,33 @@ def test_one_kernel_and_two_kernel_bounces_give_the_same_bits(camera, rtx_lib):
         assert np.array_equal(c.view(np.uint32), d.view(np.uint32)) and sc_.bounces == sd.bounces
 
 
+@pytest.mark.parametrize("cap", [None, "1", "2"], ids=["queue_default", "queue_1_per_thread", "queue_2_per_thread"])
+def test_triangle_tests_as_tasks_of_the_block_keep_the_bits(cap, rtx_lib, monkeypatch):
+    """Trees of up to 32 leaves in scenes where rays meet leaves at every turn (Cornell) have every lane test all
+    leaf boxes and the block test the (ray, leaf) pairs from a queue in LDS, for bounces and light samples alike.
+    RTX_NO_LEAF_TASKS keeps the per-lane walk, RTX_LEAF_TASKS_ALWAYS uses the tasks for sparse scenes too (leaves of
+    one triangle, overlapping triangles with equal t, spheres in front of the mesh), RTX_LEAF_TASK_CAP shrinks the
+    queue until lanes have to test their leaves themselves: same images, same counts."""
+    cases = [(scenes.cornell(), 0), (scenes.cornell(lights=4), 0), (scenes.soup(30, 3, seed=2, size=0.5), 1),
+             (scenes.soup(57, 0, seed=9, size=0.9), 1), (scenes.soup(9, 2, seed=4, size=0.9), 1)]
+    for sc, sky in cases:
+        for kw in (dict(width=200, height=120, sky=sky, pool_paths=1 << 13),
+                   dict(width=97, height=61, sky=sky, pool_paths=700, max_bounces=4, camera=2)):
+            monkeypatch.setenv("RTX_NO_LEAF_TASKS", "1")
+            monkeypatch.delenv("RTX_LEAF_TASKS_ALWAYS", raising=False)
+            monkeypatch.delenv("RTX_LEAF_TASK_CAP", raising=False)
+            a, sa, _ = gpu_render(Config(**kw), sc, 4)
+            monkeypatch.delenv("RTX_NO_LEAF_TASKS")
+            monkeypatch.setenv("RTX_LEAF_TASKS_ALWAYS", "1")
+            if cap:
+                monkeypatch.setenv("RTX_LEAF_TASK_CAP", cap)
+            b, sb, _ = gpu_render(Config(**kw), sc, 4)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (sc.name, kw)
+            assert (sa.paths, sa.bounces, sa.nee_samples, sa.shadow_rays) == (sb.paths, sb.bounces, sb.nee_samples, sb.shadow_rays)
+    monkeypatch.delenv("RTX_LEAF_TASKS_ALWAYS", raising=False)
+    monkeypatch.delenv("RTX_LEAF_TASK_CAP", raising=False)
+
+
 def test_scenes_without_emitters_skip_the_colour_state_and_keep_their_bits(oracle, rtx_lib):
     """Where no material emits and there are no lights a live path's colour is exactly 0, and the queues
     do not carry it.  An emissive material that no surface uses switches the skipping off: same image."""
