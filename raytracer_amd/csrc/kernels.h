@@ -1810,6 +1810,7 @@ __device__ __forceinline__ uint32_t leaf_boxes_met(const SceneDev& sc, const Wal
   uint32_t mask = 0;
   const uint32_t nl = sc.num_leaf_boxes;
   float4 a = sc.leaf_box[0], b = sc.leaf_box[1];
+#pragma unroll 2
   for (uint32_t l = 0; l < nl; l++) {
     const uint32_t nx = l + 1u < nl ? l + 1u : l;
     const float4 na = sc.leaf_box[2 * nx], nb = sc.leaf_box[2 * nx + 1];
