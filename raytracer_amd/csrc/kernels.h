@@ -1290,6 +1290,9 @@ __device__ __forceinline__ void shade_leave(const SceneDev& sc, PathState& p, co
       uint32_t li = (uint32_t)(ul * (float)nl);
       if (li >= nl) li = nl - 1;
       float4 L0 = sc.light0[li], L1 = sc.light1[li], L2 = sc.light2[li], L3 = sc.light3[li];
+      // (the light's emission with the rest of its record: left to itself the compiler fetches that one word
+      // after the other loads have come back, a second round trip in the middle of the bounce)
+      asm volatile("" ::"v"(L1.w));
       // Triangle::samplePoint, Obj.h:127-136
       float u0 = pcg_uniform(p.rng);
       float u1 = pcg_uniform(p.rng);
