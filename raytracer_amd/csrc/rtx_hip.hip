@@ -82,7 +82,7 @@ constexpr unsigned long long kOverlapMinSamples = 1ull << 26;
 #endif
 constexpr bool kTightEnd = RTX_TIGHT_END != 0;
 constexpr size_t kFusedSmallSceneBytes = 4096;  // k_trace_shade: scenes up to this size run 128-thread blocks
-constexpr double kLeafTaskMinLeafArea = 1.5;  // leaf boxes' surfaces / root box's surface from which the leaf-task kernels are used
+constexpr double kLeafTaskMinLeafArea = 1.2;  // leaf boxes' surfaces / root box's surface from which the leaf-task kernels are used
 constexpr uint32_t kTraceBatches = 2;  // ray batches per block of k_intersect/k_shadow (the next batch's loads overlap the current traversal)
 constexpr int kPollSlots = 4;
 
@@ -634,10 +634,11 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
   HIP_TRY(c->tri_surf.upload(ts));
   // Trees of a handful of leaves in scenes where a ray meets leaves at every turn (a closed room): the leaves' boxes as
   // a list, for the kernels that test them all and hand the triangle tests out as tasks of their block
-  // (block_closest_by_leaf_tasks; 16-bit primitive ids and slots there).  Measured: Cornell's seventeen leaves, whose
-  // boxes add up to 2.3 times the surface of the root's, bounce 13 % faster that way; soups of 16-48 triangles under the
-  // sky (0.5 times: most rays leave the tree after a node or two) 8-19 % slower.  The sum of the leaf boxes' surfaces
-  // over the root's is the number of leaf boxes a ray through the root's box meets on average.
+  // (block_closest_by_leaf_tasks; 16-bit primitive ids and slots there).  The sum of the leaf boxes' surfaces over the
+  // root's is the number of leaf boxes a ray through the root's box meets on average.  Measured (time with the tasks
+  // over time with the walk; tools/leaf_task_calibration.py): Cornell's seventeen leaves, 2.3 times the root's surface,
+  // 0.87; soups of 30 triangles of growing size under the sky: 0.36 -> 1.10, 0.89 -> 0.99, 1.75 -> 0.93, 3.2 -> 0.89,
+  // 4.6 -> 0.91.  Where most rays leave the tree after a node or two the list makes them test every leaf box for nothing.
   std::vector<float4> lb;
   if (bvh.width == 2 && nt < 65536 && !std::getenv("RTX_NO_LEAF_TASKS")) {  // (test hook)
     auto half_area = [](float lx, float hx, float ly, float hy, float lz, float hz) {
