@@ -1802,7 +1802,8 @@ __global__ __launch_bounds__(256) void k_shade_wave_append(SceneDev sc, Queue in
 // pairs do not fit tests its leaves itself.  LDS at `ws`: leaf_task_lds_bytes; the caller has set ws[0] to
 // (0, queue capacity, ...) as uint32 before its last barrier.
 struct LeafTaskHead {
-  uint32_t count, valid_end, pad0, pad1;  // pairs reserved so far; pairs [0, valid_end) are written
+  uint32_t count, valid_end;    // pairs reserved so far; pairs [0, valid_end) are written
+  uint32_t count2, valid_end2;  // the same for a second round of tasks in the same launch (no barrier to reset the first)
 };
 __host__ __device__ constexpr size_t leaf_task_lds_bytes(uint32_t block, uint32_t cap_per_thread) {
   return sizeof(LeafTaskHead) + 4 * kLeafTaskMaxLeaves + (size_t)block * (32 + 8 + 2 * cap_per_thread);
@@ -1831,6 +1832,8 @@ __device__ __forceinline__ void leaf_task_begin(const SceneDev& sc, float4* ws) 
   if (threadIdx.x == 0) {
     head->count = 0;
     head->valid_end = sc.leaf_task_cap * BLOCK;
+    head->count2 = 0;
+    head->valid_end2 = sc.leaf_task_cap * BLOCK;
   }
   if (threadIdx.x < sc.num_leaf_boxes) leaf_word[threadIdx.x] = __float_as_uint(sc.leaf_box[2 * threadIdx.x + 1].z);
 }
@@ -1903,7 +1906,7 @@ __device__ __forceinline__ void block_closest_by_leaf_tasks(const SceneDev& sc, 
 // The same for occlusion: is any triangle of the mesh hit with eps < t < tfar (mesh_any)?  A pair that finds a
 // hit sets its ray's flag; the other pairs of that ray are tested all the same (a walk would have stopped), which
 // costs little where most segments are free.  The caller has run leaf_task_begin and a barrier since the last call.
-template <int BLOCK>
+template <int BLOCK, bool SECOND = false>
 __device__ __forceinline__ bool block_any_by_leaf_tasks(const SceneDev& sc, const Geom& g, float4* ws, bool active,
                                                         f3 o, f3 d, float tfar) {
   LeafTaskHead* const head = reinterpret_cast<LeafTaskHead*>(ws);
@@ -1913,6 +1916,8 @@ __device__ __forceinline__ bool block_any_by_leaf_tasks(const SceneDev& sc, cons
   uint32_t* const flag = reinterpret_cast<uint32_t*>(ray_d + BLOCK);
   uint16_t* const tasks = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned long long*>(ray_d + BLOCK) + BLOCK);
   const uint32_t tid = threadIdx.x, cap = sc.leaf_task_cap * BLOCK;
+  uint32_t* const count = SECOND ? &head->count2 : &head->count;
+  uint32_t* const valid_end = SECOND ? &head->valid_end2 : &head->valid_end;
   uint32_t own = 0;
   if (active) {
     Walk w;
@@ -1923,7 +1928,7 @@ __device__ __forceinline__ bool block_any_by_leaf_tasks(const SceneDev& sc, cons
     flag[tid] = 0;
     if (mask != 0) {
       const uint32_t cnt = (uint32_t)__popc(mask);
-      uint32_t at = atomicAdd(&head->count, cnt);
+      uint32_t at = atomicAdd(count, cnt);
       if (at + cnt <= cap) {
         while (mask != 0) {
           const uint32_t l = (uint32_t)__builtin_ctz(mask);
@@ -1931,13 +1936,13 @@ __device__ __forceinline__ bool block_any_by_leaf_tasks(const SceneDev& sc, cons
           tasks[at++] = (uint16_t)((tid << 5) | l);
         }
       } else {
-        atomicMin(&head->valid_end, at);
+        atomicMin(valid_end, at);
         own = mask;
       }
     }
   }
   __syncthreads();
-  const uint32_t ntasks = min(head->count, head->valid_end);
+  const uint32_t ntasks = min(*count, *valid_end);
   for (uint32_t k = tid; k < ntasks; k += BLOCK) {
     const uint32_t task = tasks[k], r = task >> 5;
     const float4 O = ray_o[r], D = ray_d[r];
@@ -1960,7 +1965,7 @@ __device__ __forceinline__ bool block_any_by_leaf_tasks(const SceneDev& sc, cons
 // (eight waves per SIMD: the compiler then keeps to 96 scalar registers as well, which it passed by five
 // otherwise, and a wave of this kernel mostly waits: sample2 8.8 -> 8.3 ms, Cornell's bounces 51.7 -> 49.4)
 // (kLdsLeafTasks: its LDS workspace leaves room for seven blocks of 256 per CU, so seven waves per SIMD it is)
-template <int BLOCK, int MODE, bool LIGHTS>
+template <int BLOCK, int MODE, bool LIGHTS, bool INLINE_LIGHT_SAMPLES = false>
 __global__ __launch_bounds__(BLOCK, MODE == kLdsLeafTasks ? 7 : 8) void k_trace_shade(SceneDev sc, Queue in, Queue out, ShadowQueue sq,
                                                        SegCounter* seg, int qi, uint32_t cap, float* res,
                                                        TraceParams tp, const Primary* __restrict__ prp, Summary* sum) {
@@ -2022,6 +2027,19 @@ __global__ __launch_bounds__(BLOCK, MODE == kLdsLeafTasks ? 7 : 8) void k_trace_
     }
   }
   wave_count(bad, &sum->stat_nan);
+  bool queue_sample = want_shadow;
+  if constexpr (INLINE_LIGHT_SAMPLES) {
+    // The light sample is traced here, as a second round of tasks of the block: it is counted, not queued.
+    static_assert(MODE == kLdsLeafTasks && LIGHTS, "the block's task queue is what traces the sample");
+    if (!want_shadow) {  // (lanes without a sample bring defined values to the block's call)
+      sr.d = mk3(0.0f, 0.0f, 0.0f);
+      sr.tfar = 0.0f;
+    }
+    const bool try_light = want_shadow && !analytic_any(sc, p.o, sr.d, sr.tfar);
+    const bool occ = block_any_by_leaf_tasks<BLOCK, true>(sc, geom, task_ws, try_light, p.o, sr.d, sr.tfar);
+    if (try_light && !occ) p.col = vadd(p.col, sr.contrib);
+    queue_sample = false;
+  }
   uint32_t pos, spos = 0;  // (the per-block append of k_shade_block_append measured slower here)
   if (reserve_early) {
     const PathTicket tk = wave_reserve_paths(alive, &seg[s].c[qi ^ 1]);
@@ -2031,7 +2049,7 @@ __global__ __launch_bounds__(BLOCK, MODE == kLdsLeafTasks ? 7 : 8) void k_trace_
     wave_append(alive, want_shadow, did_nee, &seg[s].c[qi ^ 1], pos, spos);
   }
   if (alive) store_path(sc, out, s * cap + pos, p);
-  if (want_shadow) {
+  if (queue_sample) {
     const uint32_t k = s * cap + spos;
     sq.q0[k] = make_float4(p.o.x, p.o.y, p.o.z, sr.tfar);
     sq.q1[k] = make_float4(sr.d.x, sr.d.y, sr.d.z, __uint_as_float(s * cap + pos));

@@ -876,6 +876,11 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
   // 14 % for 256 at a scene of 16 KB).
   const bool few = c->trace_mode == rtx::kFewTriangles;
   const bool fused = c->cfg.fused_trace != 1 && (c->trace_mode == rtx::kLdsBvh2 || few);
+  // Rooms whose triangle tests run as tasks of the block trace a bounce's light sample in the bounce kernel as
+  // well, as a second round of tasks: no light-sample queue, no launch for it (MIS Cornell 57.4 -> 51.4 ms per
+  // frame, same bits).  RTX_QUEUE_LIGHT_SAMPLES keeps the queue and k_shadow_leaf_tasks (test hook).
+  const bool inline_light_samples = fused && !few && shadows && c->scene.num_leaf_boxes != 0 &&
+                                    std::getenv("RTX_QUEUE_LIGHT_SAMPLES") == nullptr;
   const int fused_block = c->lds_scene_bytes <= kFusedSmallSceneBytes ||
                                   (size_t)c->stack_entries * 256 * sizeof(int) + scene_lds > kLdsLaunchMaxBytes
                               ? 128
@@ -999,6 +1004,11 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
   } while (0)
       if (few)
         RTX_TRACE_SHADE(128, rtx::kFewTriangles, 0);
+      else if (inline_light_samples)           // ... and the light sample as a second round of tasks
+        rtx::k_trace_shade<256, rtx::kLdsLeafTasks, true, true>
+            <<<dim3(div_up(seg_max_upper, 256), nseg), 256,
+               scene_lds + rtx::leaf_task_lds_bytes(256, c->scene.leaf_task_cap), st>>>(
+                c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp, sum);
       else if (c->scene.num_leaf_boxes != 0)   // a handful of leaves: their triangle tests as tasks of the block
         RTX_TRACE_SHADE(256, rtx::kLdsLeafTasks, scene_lds + rtx::leaf_task_lds_bytes(256, c->scene.leaf_task_cap));
       else if (fused_block == 128)
@@ -1031,7 +1041,7 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
     lt.end();
     launches += 2;
     }
-    if (shadows) {
+    if (shadows && !inline_light_samples) {
       lt.begin(kShadow, active_upper);
       if (c->trace_mode == rtx::kGlobalBvh4 && c->shadow_refill_lanes > 0) {
         const uint32_t per_seg = std::max(1u, div_up(kWideWaves, nseg * (kTraceBlock / 64)));

@@ -193,6 +193,13 @@ def test_triangle_tests_as_tasks_of_the_block_keep_the_bits(cap, rtx_lib, monkey
             b, sb, _ = gpu_render(Config(**kw), sc, 4)
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (sc.name, kw)
             assert (sa.paths, sa.bounces, sa.nee_samples, sa.shadow_rays) == (sb.paths, sb.bounces, sb.nee_samples, sb.shadow_rays)
+            # (b traced its light samples inside the bounce kernel, as a second round of tasks; with them queued
+            # for k_shadow_leaf_tasks instead:)
+            monkeypatch.setenv("RTX_QUEUE_LIGHT_SAMPLES", "1")
+            q, sq_, _ = gpu_render(Config(**kw), sc, 4)
+            monkeypatch.delenv("RTX_QUEUE_LIGHT_SAMPLES")
+            assert np.array_equal(a.view(np.uint32), q.view(np.uint32)), (sc.name, kw, "queued light samples")
+            assert (sa.paths, sa.bounces, sa.nee_samples, sa.shadow_rays) == (sq_.paths, sq_.bounces, sq_.nee_samples, sq_.shadow_rays)
     monkeypatch.delenv("RTX_LEAF_TASKS_ALWAYS", raising=False)
     monkeypatch.delenv("RTX_LEAF_TASK_CAP", raising=False)
 
