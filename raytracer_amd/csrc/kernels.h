@@ -121,7 +121,9 @@ struct SegCounter {
   unsigned long long gen_ordinal0;
   uint32_t grab;                      // rays of the segment handed out so far (k_intersect_wide); k_plan clears it
   uint32_t grab_shadow;               // the same for its light samples (k_shadow_wide)
-  unsigned long long pad[11];
+  uint32_t more_bounces;              // bounces a launch made beyond the first of each of its paths (k_trace_shade, BOUNCES > 1)
+  uint32_t pad32;
+  unsigned long long pad[10];
 };
 static_assert(sizeof(SegCounter) == 128, "one line per segment");
 constexpr int kPathBits = 21, kShadowBits = 21;
@@ -1403,6 +1405,7 @@ __global__ void k_begin(SegCounter* seg, Summary* sum, uint32_t nseg, unsigned l
     seg[s].gen_ordinal0 = 0;
     seg[s].grab = 0;
     seg[s].grab_shadow = 0;
+    seg[s].more_bounces = 0;
   }
   if (s == 0) {
     *pr_out = pr;  // camera and sample numbering of this call, for the kernels that recompute primary rays
@@ -1444,7 +1447,7 @@ __global__ __launch_bounds__(1024) void k_plan(SegCounter* seg, Summary* sum, in
     sh = seg_shadow(c);
     ne = seg_nee(c);
     room = cap - n;
-    if (qd >= 0) drained = seg_paths(seg[s].c[qd]);
+    if (qd >= 0) drained = seg_paths(seg[s].c[qd]) + seg[s].more_bounces;
   }
   // inclusive scan of the room within the wave
   unsigned long long incl = room;
@@ -1471,6 +1474,7 @@ __global__ __launch_bounds__(1024) void k_plan(SegCounter* seg, Summary* sum, in
     seg[s].c[qf] = (unsigned long long)(n + g);
     seg[s].grab = 0;
     seg[s].grab_shadow = 0;
+    seg[s].more_bounces = 0;
     if (qd >= 0) seg[s].c[qd] = 0;
   }
   // sums of g, shadow rays, light samples and drained paths; maximum of n + g
@@ -1965,7 +1969,12 @@ __device__ __forceinline__ bool block_any_by_leaf_tasks(const SceneDev& sc, cons
 // (eight waves per SIMD: the compiler then keeps to 96 scalar registers as well, which it passed by five
 // otherwise, and a wave of this kernel mostly waits: sample2 8.8 -> 8.3 ms, Cornell's bounces 51.7 -> 49.4)
 // (kLdsLeafTasks: its LDS workspace leaves room for seven blocks of 256 per CU, so seven waves per SIMD it is)
-template <int BLOCK, int MODE, bool LIGHTS, bool INLINE_LIGHT_SAMPLES = false>
+// BOUNCES = 2 (light-free scenes without a tree): a path that goes on after the launch's first bounce makes its
+// second in the same lane.  Such a kernel moves bytes more than it computes (a path is 48 B read and 48 B written per
+// bounce, and four in ten go on), and every second write and read back of a path falls away; the lanes of the
+// paths that ended idle through the second bounce, which costs less than the bytes (sample2 8.0 -> 7.0 ms frame by
+// frame; three bounces per launch: 9.0).
+template <int BLOCK, int MODE, bool LIGHTS, bool INLINE_LIGHT_SAMPLES = false, int BOUNCES = 1>
 __global__ __launch_bounds__(BLOCK, MODE == kLdsLeafTasks ? 7 : 8) void k_trace_shade(SceneDev sc, Queue in, Queue out, ShadowQueue sq,
                                                        SegCounter* seg, int qi, uint32_t cap, float* res,
                                                        TraceParams tp, const Primary* __restrict__ prp, Summary* sum) {
@@ -2014,16 +2023,37 @@ __global__ __launch_bounds__(BLOCK, MODE == kLdsLeafTasks ? 7 : 8) void k_trace_
   // known once the roulette is through: the slots are reserved there and the atomic's round trip runs beside
   // the sampling of the next direction.
   constexpr bool reserve_early = !LIGHTS;  // (LIGHTS: the scene has any, sc.num_lights != 0)
-  if (active) {
-    if constexpr (MODE != kLdsLeafTasks) {
+  bool live = active;  // this lane carries a path
+  if constexpr (MODE != kLdsLeafTasks) {
+    if (active)
       load_path(sc, in, i, j >= seg[s].gen_slot0, *prp, (uint32_t)seg[s].gen_ordinal0 + (j - seg[s].gen_slot0), p);
-      cast_ray<WALK>(sc, geom, p.o, p.d, stk, t, id);
+    if constexpr (BOUNCES > 1) {
+      // The first BOUNCES - 1 bounces of a launch: a path that goes on stays in its lane (its state is neither
+      // written nor read back), the lanes of the paths that ended idle.  Counted in seg[s].more_bounces.
+      static_assert(!LIGHTS, "a bounce that samples a light queues the sample against the path's slot");
+#pragma unroll 1
+      for (int b = 1; b < BOUNCES; b++) {
+        bool goes_on = false;
+        if (live) {
+          cast_ray<WALK>(sc, geom, p.o, p.d, stk, t, id);
+          goes_on = shade_bounce(sc, global_geom(sc), p, t, id, want_shadow, did_nee, sr);
+          if (!goes_on) {
+            store_result(res, p.ordinal, p.col);
+            bad = bad || colour_not_finite(p.col);
+          }
+        }
+        live = goes_on;
+        wave_count(live, &seg[s].more_bounces);
+      }
     }
+  }
+  if (live) {
+    if constexpr (MODE != kLdsLeafTasks) cast_ray<WALK>(sc, geom, p.o, p.d, stk, t, id);
     alive = reserve_early ? shade_arrive<true>(sc, global_geom(sc), p, t, id, sh)
                           : shade_bounce(sc, global_geom(sc), p, t, id, want_shadow, did_nee, sr);
     if (!alive) {
       store_result(res, p.ordinal, p.col);
-      bad = colour_not_finite(p.col);
+      bad = bad || colour_not_finite(p.col);
     }
   }
   wave_count(bad, &sum->stat_nan);

@@ -881,6 +881,10 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
   // frame, same bits).  RTX_QUEUE_LIGHT_SAMPLES keeps the queue and k_shadow_leaf_tasks (test hook).
   const bool inline_light_samples = fused && !few && shadows && c->scene.num_leaf_boxes != 0 &&
                                     std::getenv("RTX_QUEUE_LIGHT_SAMPLES") == nullptr;
+  // Light-free scenes without a tree make two bounces per launch (k_trace_shade, BOUNCES); RTX_FEW_BOUNCES=1: one
+  // (the hook of the test that compares the two).
+  int few_bounces = 2;
+  if (const char* e = std::getenv("RTX_FEW_BOUNCES")) few_bounces = std::atoi(e) == 1 ? 1 : 2;
   const int fused_block = c->lds_scene_bytes <= kFusedSmallSceneBytes ||
                                   (size_t)c->stack_entries * 256 * sizeof(int) + scene_lds > kLdsLaunchMaxBytes
                               ? 128
@@ -1002,7 +1006,10 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
       rtx::k_trace_shade<B, M, false><<<dim3(div_up(seg_max_upper, B), nseg), B, LDS, st>>>(                      \
           c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp, sum);                                           \
   } while (0)
-      if (few)
+      if (few && c->scene.num_lights == 0 && few_bounces == 2)  // two bounces per launch
+        rtx::k_trace_shade<128, rtx::kFewTriangles, false, false, 2><<<dim3(div_up(seg_max_upper, 128), nseg), 128, 0, st>>>(
+            c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp, sum);
+      else if (few)
         RTX_TRACE_SHADE(128, rtx::kFewTriangles, 0);
       else if (inline_light_samples)           // ... and the light sample as a second round of tasks
         rtx::k_trace_shade<256, rtx::kLdsLeafTasks, true, true>

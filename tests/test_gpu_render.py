@@ -170,6 +170,26 @@ def test_one_kernel_and_two_kernel_bounces_give_the_same_bits(camera, rtx_lib):
         assert np.array_equal(c.view(np.uint32), d.view(np.uint32)) and sc_.bounces == sd.bounces
 
 
+def test_two_bounces_per_launch_keep_the_bits(rtx_lib, monkeypatch):
+    """Light-free scenes whose mesh is tested without a tree (the reference's sphere scenes) make two bounces per
+    launch of the bounce kernel: a path that goes on after the first stays in its lane.  RTX_FEW_BOUNCES=1 keeps one
+    bounce per launch: same images, same counts (the second bounces are counted apart from the queue fills), with
+    every camera, a bounce limit of one, two and five, and a pool smaller than a wave's worth of segments."""
+    for sc in (scenes.sphere_sky(glass=True), scenes.sphere_sky(glass=False)):
+        for kw in (dict(width=200, height=120, sky=1, pool_paths=1 << 13),
+                   dict(width=97, height=61, sky=1, pool_paths=700, max_bounces=5, camera=1, fov=60.0),
+                   dict(width=64, height=48, sky=1, pool_paths=1 << 12, max_bounces=1),
+                   dict(width=64, height=48, sky=1, pool_paths=1 << 12, max_bounces=2, camera=2),
+                   dict(width=80, height=50, sky=0, pool_paths=1 << 12, primary_rays=1)):
+            monkeypatch.setenv("RTX_FEW_BOUNCES", "1")
+            a, sa, _ = gpu_render(Config(**kw), sc, 6)
+            monkeypatch.delenv("RTX_FEW_BOUNCES")
+            b, sb, _ = gpu_render(Config(**kw), sc, 6)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (sc.name, kw)
+            assert (sa.paths, sa.bounces, sa.nee_samples, sa.shadow_rays, sa.nan_paths) == \
+                   (sb.paths, sb.bounces, sb.nee_samples, sb.shadow_rays, sb.nan_paths), (sc.name, kw)
+
+
 @pytest.mark.parametrize("cap", [None, "1", "2"], ids=["queue_default", "queue_1_per_thread", "queue_2_per_thread"])
 def test_triangle_tests_as_tasks_of_the_block_keep_the_bits(cap, rtx_lib, monkeypatch):
     """Trees of up to 32 leaves in scenes where rays meet leaves at every turn (Cornell) have every lane test all
