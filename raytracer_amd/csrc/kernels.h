@@ -1974,10 +1974,25 @@ __device__ __forceinline__ bool block_any_by_leaf_tasks(const SceneDev& sc, cons
 // bounce, and four in ten go on), and every second write and read back of a path falls away; the lanes of the
 // paths that ended idle through the second bounce, which costs less than the bytes (sample2 8.0 -> 7.0 ms frame by
 // frame; three bounces per launch: 9.0).
-template <int BLOCK, int MODE, bool LIGHTS, bool INLINE_LIGHT_SAMPLES = false, int BOUNCES = 1>
+template <int BLOCK, int MODE, bool LIGHTS, bool INLINE_LIGHT_SAMPLES = false, int BOUNCES = 1, int PLAIN = 0>
 __global__ __launch_bounds__(BLOCK, MODE == kLdsLeafTasks ? 7 : 8) void k_trace_shade(SceneDev sc, Queue in, Queue out, ShadowQueue sq,
                                                        SegCounter* seg, int qi, uint32_t cap, float* res,
                                                        TraceParams tp, const Primary* __restrict__ prp, Summary* sum) {
+  // PLAIN >= 1: the host has seen that the scene has no boxes and no planes and that the call is the path tracer
+  // without a bounce limit (what the reference's scenes are): with these known when the kernel is built, their
+  // branches, and the scalar registers that held their operands, are gone.  PLAIN == 2: under the sky as well, with
+  // nothing that emits and a handful of surfaces (the reference's sphere scenes).
+  if constexpr (PLAIN >= 1) {
+    sc.num_boxes = 0;
+    sc.num_planes = 0;
+    sc.integrator = 0;
+    sc.max_bounces = 0;
+  }
+  if constexpr (PLAIN == 2) {
+    sc.sky = 1;
+    sc.carries_colour = 0;
+    sc.few_surfaces = 1;
+  }
   const uint32_t s = blockIdx.y;
   const uint32_t n = seg_paths(seg[s].c[qi]);
   if (blockIdx.x * BLOCK >= n) return;  // whole blocks beyond the fill leave; the rest stay for the barrier and the ballots

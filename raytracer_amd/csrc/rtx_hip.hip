@@ -884,6 +884,10 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
   // Light-free scenes without a tree make two bounces per launch (k_trace_shade, BOUNCES); RTX_FEW_BOUNCES=1: one
   // (the hook of the test that compares the two).
   int few_bounces = 2;
+  // (a scene of triangles and spheres, path-traced without a bounce limit: kernels built for exactly that)
+  const bool plain = c->scene.num_boxes == 0 && c->scene.num_planes == 0 && c->scene.integrator == 0 &&
+                     c->scene.max_bounces == 0 && std::getenv("RTX_NO_PLAIN_KERNELS") == nullptr;
+  const bool open_sky = c->scene.sky == 1 && c->scene.carries_colour == 0 && c->scene.few_surfaces == 1;
   if (const char* e = std::getenv("RTX_FEW_BOUNCES")) few_bounces = std::atoi(e) == 1 ? 1 : 2;
   const int fused_block = c->lds_scene_bytes <= kFusedSmallSceneBytes ||
                                   (size_t)c->stack_entries * 256 * sizeof(int) + scene_lds > kLdsLaunchMaxBytes
@@ -1006,7 +1010,13 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
       rtx::k_trace_shade<B, M, false><<<dim3(div_up(seg_max_upper, B), nseg), B, LDS, st>>>(                      \
           c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp, sum);                                           \
   } while (0)
-      if (few && c->scene.num_lights == 0 && few_bounces == 2)  // two bounces per launch
+      if (few && c->scene.num_lights == 0 && few_bounces == 2 && plain && open_sky)  // two bounces per launch
+        rtx::k_trace_shade<128, rtx::kFewTriangles, false, false, 2, 2><<<dim3(div_up(seg_max_upper, 128), nseg), 128, 0, st>>>(
+            c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp, sum);
+      else if (few && c->scene.num_lights == 0 && few_bounces == 2 && plain)
+        rtx::k_trace_shade<128, rtx::kFewTriangles, false, false, 2, 1><<<dim3(div_up(seg_max_upper, 128), nseg), 128, 0, st>>>(
+            c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp, sum);
+      else if (few && c->scene.num_lights == 0 && few_bounces == 2)
         rtx::k_trace_shade<128, rtx::kFewTriangles, false, false, 2><<<dim3(div_up(seg_max_upper, 128), nseg), 128, 0, st>>>(
             c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp, sum);
       else if (few)

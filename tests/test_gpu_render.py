@@ -188,6 +188,13 @@ def test_two_bounces_per_launch_keep_the_bits(rtx_lib, monkeypatch):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (sc.name, kw)
             assert (sa.paths, sa.bounces, sa.nee_samples, sa.shadow_rays, sa.nan_paths) == \
                    (sb.paths, sb.bounces, sb.nee_samples, sb.shadow_rays, sb.nan_paths), (sc.name, kw)
+            # (b ran kernels built for what the scene and the call are not: no boxes, no planes, no bounce limit, and
+            # for the first case the open sky with nothing that emits; the general build of the same kernel:)
+            monkeypatch.setenv("RTX_NO_PLAIN_KERNELS", "1")
+            g, sg, _ = gpu_render(Config(**kw), sc, 6)
+            monkeypatch.delenv("RTX_NO_PLAIN_KERNELS")
+            assert np.array_equal(b.view(np.uint32), g.view(np.uint32)), (sc.name, kw, "general build")
+            assert (sg.paths, sg.bounces) == (sb.paths, sb.bounces)
 
 
 @pytest.mark.parametrize("cap", [None, "1", "2"], ids=["queue_default", "queue_1_per_thread", "queue_2_per_thread"])
