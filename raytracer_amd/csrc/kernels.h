@@ -2281,10 +2281,21 @@ __global__ __launch_bounds__(BLOCK, 8) void k_shadow_wide(SceneDev sc, Queue pat
 // kernels is all launch latency.  Every lane leaves after at most kFinishCap
 // bounces (a path that long has probability below 0.99^65536).
 constexpr uint32_t kFinishCap = 65536;
-template <int BLOCK, int MODE>
+template <int BLOCK, int MODE, int PLAIN = 0>
 __global__ __launch_bounds__(BLOCK) void k_finish(SceneDev sc, Queue q, const SegCounter* seg, int qi,
                                                   uint32_t cap, float* res, Summary* sum,
                                                   TraceParams tp, const Primary* __restrict__ prp) {
+  if constexpr (PLAIN >= 1) {  // (as in k_trace_shade: what the host has seen the scene and the call not to be)
+    sc.num_boxes = 0;
+    sc.num_planes = 0;
+    sc.integrator = 0;
+    sc.max_bounces = 0;
+  }
+  if constexpr (PLAIN == 2) {
+    sc.sky = 1;
+    sc.carries_colour = 0;
+    sc.few_surfaces = 1;
+  }
   RTX_TRACE_PROLOGUE();
   const uint32_t s = blockIdx.y;
   const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;

@@ -976,9 +976,14 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
         reduce_split = true;
       }
       lt.begin(kFinish, active_upper);
-      RTX_BY_MODE(c->trace_mode, rtx::k_finish, kFinishBlock,
-                  (dim3(div_up(seg_max_upper, kFinishBlock), nseg), kFinishBlock, lds_fin, st),
-                  (c->scene, queue_of(c, cur), seg, cur, cap, c->res.p, sum, tp, prp));
+      if (few && plain && open_sky && c->scene.num_lights == 0)
+        rtx::k_finish<kFinishBlock, rtx::kFewTriangles, 2><<<dim3(div_up(seg_max_upper, kFinishBlock), nseg), kFinishBlock,
+                                                             lds_fin, st>>>(c->scene, queue_of(c, cur), seg, cur, cap,
+                                                                            c->res.p, sum, tp, prp);
+      else
+        RTX_BY_MODE(c->trace_mode, rtx::k_finish, kFinishBlock,
+                    (dim3(div_up(seg_max_upper, kFinishBlock), nseg), kFinishBlock, lds_fin, st),
+                    (c->scene, queue_of(c, cur), seg, cur, cap, c->res.p, sum, tp, prp));
       lt.end();
       launches++;
       if (reduce_split) {
@@ -1021,7 +1026,12 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
             c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp, sum);
       else if (few)
         RTX_TRACE_SHADE(128, rtx::kFewTriangles, 0);
-      else if (inline_light_samples)           // ... and the light sample as a second round of tasks
+      else if (inline_light_samples && plain)  // ... and the light sample as a second round of tasks
+        rtx::k_trace_shade<256, rtx::kLdsLeafTasks, true, true, 1, 1>
+            <<<dim3(div_up(seg_max_upper, 256), nseg), 256,
+               scene_lds + rtx::leaf_task_lds_bytes(256, c->scene.leaf_task_cap), st>>>(
+                c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp, sum);
+      else if (inline_light_samples)
         rtx::k_trace_shade<256, rtx::kLdsLeafTasks, true, true>
             <<<dim3(div_up(seg_max_upper, 256), nseg), 256,
                scene_lds + rtx::leaf_task_lds_bytes(256, c->scene.leaf_task_cap), st>>>(
