@@ -2349,20 +2349,21 @@ __global__ __launch_bounds__(256) void k_reduce(const float* res, float* accum, 
   // Four floats per lane (16-byte loads) when the band allows it; the additions
   // of one float stay in sample order either way.
   if ((nfloats & 3u) == 0) {
+    // (a grid smaller than the band: each lane takes several groups of four floats, one after the other)
     const uint32_t n4 = nfloats >> 2;
-    uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= n4) return;
-    float4 acc = reinterpret_cast<const float4*>(accum)[f];
-    const float4* src = reinterpret_cast<const float4*>(res) + f;
+    for (uint32_t f = blockIdx.x * blockDim.x + threadIdx.x; f < n4; f += gridDim.x * blockDim.x) {
+      float4 acc = reinterpret_cast<const float4*>(accum)[f];
+      const float4* src = reinterpret_cast<const float4*>(res) + f;
 #pragma unroll 8
-    for (uint32_t s = 0; s < spp_chunk; s++) {
-      float4 v = src[(size_t)s * n4];
-      acc.x += v.x;
-      acc.y += v.y;
-      acc.z += v.z;
-      acc.w += v.w;
+      for (uint32_t s = 0; s < spp_chunk; s++) {
+        float4 v = src[(size_t)s * n4];
+        acc.x += v.x;
+        acc.y += v.y;
+        acc.z += v.z;
+        acc.w += v.w;
+      }
+      reinterpret_cast<float4*>(accum)[f] = acc;
     }
-    reinterpret_cast<float4*>(accum)[f] = acc;
     return;
   }
   uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;

@@ -1133,7 +1133,19 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
     HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
     rtx::k_reduce_tail<<<div_up(nfloats / 4, 256), 256, 0, st>>>(c->res.p, accum_band, c->stop4.p, nfloats, spp);
   } else {
-    rtx::k_reduce<<<div_up(nfloats, 256), 256, 0, st>>>(c->res.p, accum_band, nfloats, spp);
+    // The sum of a frame left in flight runs beside the next frame's rounds.  At full width it takes the memory
+    // system for itself (5.7 TB/s) and the bounce kernel beside it, which lives on short round trips, stands still
+    // for as long: 0.6 of sample2's 5.8 ms.  On 64 blocks it trickles along at about 1 TB/s (its lanes wait for
+    // their own loads), more than any workload produces results at, and the rounds beside it lose little:
+    // sample2 5.79 -> 5.63 ms per frame; 3072 to 256 blocks change nothing, 32 are no better.  Same additions in
+    // the same order.  RTX_REDUCE_BLOCKS: another width (0: the full one).
+    uint32_t blocks = div_up(nfloats, 256);
+    if (detach && (nfloats & 3u) == 0) {
+      uint32_t narrow = 64;
+      if (const char* e = std::getenv("RTX_REDUCE_BLOCKS")) narrow = (uint32_t)std::atoi(e);
+      if (narrow != 0) blocks = std::min(blocks, narrow);
+    }
+    rtx::k_reduce<<<blocks, 256, 0, st>>>(c->res.p, accum_band, nfloats, spp);
   }
   lt.end();
   launches++;
