@@ -68,3 +68,13 @@ def test_random_case(seed, oracle, rtx_lib):
         # one of them stays 205 bounces longer between the spheres.  One such chain per 2000 paths is allowed.
         chains = 300 * (1 + st.paths // 2000)
         assert abs(st.bounces - ost.bounces) <= max(0.02 * ost.bounces, 20) + chains, (seed, kw, st.bounces, ost.bounces)
+
+
+def test_random_rooms_with_lights_keep_their_bits_across_kernels(rtx_lib):
+    """Random rooms with lights (tools/room_fuzz.py): the bounce kernel that traces its light samples itself, its
+    general build, the queued light samples and the per-lane walk give the same image bits and counts."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import room_fuzz
+    assert room_fuzz.differences(0, 16) == 0
