@@ -78,3 +78,13 @@ def test_random_rooms_with_lights_keep_their_bits_across_kernels(rtx_lib):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import room_fuzz
     assert room_fuzz.differences(0, 16) == 0
+
+
+def test_random_scenes_without_a_tree_keep_their_bits_across_kernels(rtx_lib):
+    """Random light-free scenes of a few triangles and spheres (tools/few_fuzz.py): two bounces per launch, one bounce
+    per launch and the general build of the kernels give the same image bits and counts."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import few_fuzz
+    assert few_fuzz.differences(0, 24) == 0
