@@ -158,6 +158,12 @@ typedef struct {
   uint64_t drain_launches;   /* chunks that ended in the drain kernel (one launch that runs the last paths to
                                 their ends) */
   uint64_t overlapped_sums;  /* ... of which the ordered sum ran beside that kernel on a second stream */
+  uint64_t stored_paths;     /* paths a bounce wrote to a queue and the next launch read back (a bounce follows a fresh
+                                sample, such a round trip through memory, or, where a launch makes two bounces, the
+                                bounce before it in the same lane) */
+  uint64_t device_allocations; /* hipMalloc calls this library has made in this process so far, over all contexts
+                                (not cleared by rtx_reset_stats): unchanged across a call means the call allocated
+                                no device memory */
 } rtx_stats;
 
 typedef struct {
@@ -298,6 +304,28 @@ int rtx_accum_clear(rtx_ctx* ctx, float* accum_dev, void* stream);
  * with sample_base = the number of samples they hold gives the bits of an uninterrupted one.
  * Synchronous. */
 int rtx_accum_upload(rtx_ctx* ctx, float* accum_dev, const float* sums_host, void* stream);
+
+/*
+ * Environment variables (test and tuning hooks, not part of the contract).
+ *
+ * rtx_create reads the following variables once and keeps what it found in the context; no other
+ * entry point looks at the environment.  Each selects between two code paths that produce the
+ * same bits (the GPU tests render with both and compare), or sets a tuning constant; none changes
+ * what the library computes.  Production callers leave them unset.
+ *   RTX_NO_LEAF_TASKS        rooms of a few surfaces: per-lane walk instead of the block's task queue
+ *   RTX_LEAF_TASKS_ALWAYS    ... the task queue for sparse small scenes as well
+ *   RTX_LEAF_TASK_CAP=n      (ray, leaf) pairs per thread that queue holds (default 8; 1 forces the fallback)
+ *   RTX_QUEUE_LIGHT_SAMPLES  rooms: light samples queued for a kernel of their own instead of traced in the bounce kernel
+ *   RTX_NO_FEW_TRIANGLES     meshes of up to 8 triangles get a tree like larger ones
+ *   RTX_NO_LDS_SCENE         small trees stay in global memory instead of LDS
+ *   RTX_LDS_SCENE_MAX_KB=n   size up to which a tree is staged in LDS (default 24)
+ *   RTX_NO_PLAIN_KERNELS     the general build of the bounce and drain kernels for every scene
+ *   RTX_FEW_BOUNCES=1        one bounce per launch where two are the default
+ *   RTX_WIDE_REFILL_LANES=n, RTX_SHADOW_REFILL_LANES=n
+ *                            idle lanes at which a wave of the wide-tree kernels takes new rays
+ *   RTX_REDUCE_BLOCKS=n      width of the ordered sum of a frame left in flight (0: full width)
+ *   RTX_OVERLAP_MIN_SAMPLES=n  chunk size from which the ordered sum runs beside the drain kernel
+ */
 
 #ifdef __cplusplus
 }

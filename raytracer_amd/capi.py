@@ -77,6 +77,7 @@ class Stats(C.Structure):
         ("timed_launches_shadow", C.c_uint64), ("timed_launches_generate", C.c_uint64),
         ("nan_paths", C.c_uint64), ("truncated_paths", C.c_uint64),
         ("drain_launches", C.c_uint64), ("overlapped_sums", C.c_uint64),
+        ("stored_paths", C.c_uint64), ("device_allocations", C.c_uint64),
     ]
 
     def as_dict(self) -> dict:

@@ -137,6 +137,7 @@ struct Summary {
   unsigned long long next_sample;    // ordinal of the next sample to generate
   unsigned long long total_samples;  // band_pixels * spp of this chunk
   unsigned long long stat_paths, stat_bounces, stat_nee, stat_shadow;
+  unsigned long long stat_stored;  // paths a bounce wrote to a queue for the next launch to read back
   uint32_t active_total;  // paths in the queue about to be traced
   uint32_t active_max;    // the fullest segment
   uint32_t stat_nan;        // finished paths whose colour has a NaN or an infinity in it
@@ -1412,6 +1413,7 @@ __global__ void k_begin(SegCounter* seg, Summary* sum, uint32_t nseg, unsigned l
     sum->next_sample = 0;
     sum->total_samples = total_samples;
     sum->stat_paths = sum->stat_bounces = sum->stat_nee = sum->stat_shadow = 0;
+    sum->stat_stored = 0;
     sum->active_total = 0;
     sum->active_max = 0;
     sum->stat_nan = 0;
@@ -1428,14 +1430,15 @@ __global__ __launch_bounds__(1024) void k_plan(SegCounter* seg, Summary* sum, in
   // blockDim.x is a multiple of 64 that covers nseg.  Scans and sums go through the lanes of a
   // wave with shuffles and across the (at most 16) waves through LDS: three barriers in all.
   __shared__ unsigned long long wave_room[16];
-  __shared__ uint32_t wave_part[16][5];
+  __shared__ uint32_t wave_part[16][6];
   const uint32_t s = threadIdx.x, lane = s & 63u, wave = s >> 6, nwaves = blockDim.x >> 6;
   uint32_t n = 0, sh = 0, ne = 0, drained = 0, room = 0;
   // Everything this block reads is requested here, ahead of the first barrier, so that the loads share one
   // round trip (the kernel is a chain of dependent steps between two rounds with the whole chip waiting on it).
   const unsigned long long next = sum->next_sample, total = sum->total_samples;
-  unsigned long long stat_paths = 0, stat_bounces = 0, stat_shadow = 0, stat_nee = 0;
+  unsigned long long stat_paths = 0, stat_bounces = 0, stat_shadow = 0, stat_nee = 0, stat_stored = 0;
   if (s == 0) {
+    stat_stored = sum->stat_stored;
     stat_paths = sum->stat_paths;
     stat_bounces = sum->stat_bounces;
     stat_shadow = sum->stat_shadow;
@@ -1477,8 +1480,8 @@ __global__ __launch_bounds__(1024) void k_plan(SegCounter* seg, Summary* sum, in
     seg[s].more_bounces = 0;
     if (qd >= 0) seg[s].c[qd] = 0;
   }
-  // sums of g, shadow rays, light samples and drained paths; maximum of n + g
-  uint32_t v0 = g, v1 = n + g, v2 = sh, v3 = ne, v4 = drained;
+  // sums of g, shadow rays, light samples, drained paths and the paths the round stored; maximum of n + g
+  uint32_t v0 = g, v1 = n + g, v2 = sh, v3 = ne, v4 = drained, v5 = n;
   for (int off = 32; off > 0; off >>= 1) {
     v0 += __shfl_down(v0, off, 64);
     const uint32_t o1 = __shfl_down(v1, off, 64);
@@ -1486,8 +1489,10 @@ __global__ __launch_bounds__(1024) void k_plan(SegCounter* seg, Summary* sum, in
     v2 += __shfl_down(v2, off, 64);
     v3 += __shfl_down(v3, off, 64);
     v4 += __shfl_down(v4, off, 64);
+    v5 += __shfl_down(v5, off, 64);
   }
   if (lane == 0) {
+    wave_part[wave][5] = v5;
     wave_part[wave][0] = v0;
     wave_part[wave][1] = v1;
     wave_part[wave][2] = v2;
@@ -1496,7 +1501,7 @@ __global__ __launch_bounds__(1024) void k_plan(SegCounter* seg, Summary* sum, in
   }
   __syncthreads();
   if (s == 0) {
-    unsigned long long gen_total = 0, shadow_total = 0, nee_total = 0, drained_total = 0;
+    unsigned long long gen_total = 0, shadow_total = 0, nee_total = 0, drained_total = 0, stored_total = 0;
     uint32_t fill_max = 0;
     for (uint32_t w = 0; w < nwaves; w++) {
       gen_total += wave_part[w][0];
@@ -1504,12 +1509,14 @@ __global__ __launch_bounds__(1024) void k_plan(SegCounter* seg, Summary* sum, in
       shadow_total += wave_part[w][2];
       nee_total += wave_part[w][3];
       drained_total += wave_part[w][4];
+      stored_total += wave_part[w][5];
     }
     sum->next_sample = next + gen_total;
     sum->stat_paths = stat_paths + gen_total;
     sum->stat_bounces = stat_bounces + drained_total;
     sum->stat_shadow = stat_shadow + shadow_total;
     sum->stat_nee = stat_nee + nee_total;
+    sum->stat_stored = stat_stored + stored_total;
     sum->active_total = (uint32_t)((unsigned long long)nseg * cap - room_total + gen_total);
     sum->active_max = fill_max;
   }
@@ -1809,8 +1816,11 @@ struct LeafTaskHead {
   uint32_t count, valid_end;    // pairs reserved so far; pairs [0, valid_end) are written
   uint32_t count2, valid_end2;  // the same for a second round of tasks in the same launch (no barrier to reset the first)
 };
+// head | leaf words | ray origins | ray directions | closest-hit keys (flags of a first any-hit round) | pairs | flags
+// of a second round.  The second round's flags have words of their own: a lane that enters the second round writes
+// its flag while another wave may still be reading its ray's key of the first.
 __host__ __device__ constexpr size_t leaf_task_lds_bytes(uint32_t block, uint32_t cap_per_thread) {
-  return sizeof(LeafTaskHead) + 4 * kLeafTaskMaxLeaves + (size_t)block * (32 + 8 + 2 * cap_per_thread);
+  return sizeof(LeafTaskHead) + 4 * kLeafTaskMaxLeaves + (size_t)block * (32 + 8 + 2 * cap_per_thread + 4);
 }
 // Bit l set: the ray of walk `w` meets the box of leaf l between w.tmin and tmax.  The boxes come through the
 // scalar cache; each is requested one test ahead, so that a test does not begin with a wait for its operands.
@@ -1917,9 +1927,9 @@ __device__ __forceinline__ bool block_any_by_leaf_tasks(const SceneDev& sc, cons
   uint32_t* const leaf_word = reinterpret_cast<uint32_t*>(ws + 1);
   float4* const ray_o = ws + 1 + kLeafTaskMaxLeaves / 4;
   float4* const ray_d = ray_o + BLOCK;
-  uint32_t* const flag = reinterpret_cast<uint32_t*>(ray_d + BLOCK);
   uint16_t* const tasks = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned long long*>(ray_d + BLOCK) + BLOCK);
   const uint32_t tid = threadIdx.x, cap = sc.leaf_task_cap * BLOCK;
+  uint32_t* const flag = SECOND ? reinterpret_cast<uint32_t*>(tasks + cap) : reinterpret_cast<uint32_t*>(ray_d + BLOCK);
   uint32_t* const count = SECOND ? &head->count2 : &head->count;
   uint32_t* const valid_end = SECOND ? &head->valid_end2 : &head->valid_end;
   uint32_t own = 0;

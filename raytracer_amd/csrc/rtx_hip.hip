@@ -8,6 +8,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -110,6 +111,10 @@ int resolve_scratch(int dev) {  // the device `dev` is current
   return RTX_OK;
 }
 
+// hipMalloc calls made by this library in this process (rtx_stats.device_allocations): what the test of the
+// entry point that allocates nothing watches.
+std::atomic<uint64_t> g_device_allocations{0};
+
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
@@ -119,6 +124,7 @@ struct DevBuf {
   hipError_t alloc(size_t count) {
     release();
     if (count == 0) return hipSuccess;
+    g_device_allocations.fetch_add(1, std::memory_order_relaxed);
     hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
     if (e != hipSuccess) {
       p = nullptr;
@@ -189,10 +195,56 @@ struct StageTimer {
   std::vector<uint64_t> units;
 };
 
+// Test and tuning hooks (include/rtx_capi.h lists them).  The environment is read once, by rtx_create, into this
+// record; nothing on the render or set-scene path looks at the environment.  Each hook selects between two code
+// paths that give the same bits, or sets a tuning constant: none changes what the library computes.
+struct Hooks {
+  bool no_leaf_tasks = false;        // RTX_NO_LEAF_TASKS: rooms of a few surfaces keep the per-lane walk
+  bool leaf_tasks_always = false;    // RTX_LEAF_TASKS_ALWAYS: ... and sparse scenes use the block's task queue too
+  int leaf_task_cap = 0;             // RTX_LEAF_TASK_CAP: (ray, leaf) pairs per thread in that queue (0: default)
+  bool no_few_triangles = false;     // RTX_NO_FEW_TRIANGLES: meshes of up to 8 triangles get a tree like any other
+  bool no_lds_scene = false;         // RTX_NO_LDS_SCENE: small trees stay in global memory
+  bool queue_light_samples = false;  // RTX_QUEUE_LIGHT_SAMPLES: rooms queue their light samples for a kernel of its own
+  bool no_plain_kernels = false;     // RTX_NO_PLAIN_KERNELS: the general build of the bounce and drain kernels
+  int few_bounces = 2;               // RTX_FEW_BOUNCES=1: one bounce per launch where two are the default
+  long lds_scene_max_kb = -1;        // RTX_LDS_SCENE_MAX_KB: size up to which a tree is staged in LDS
+  int wide_refill_lanes = -1;        // RTX_WIDE_REFILL_LANES, RTX_SHADOW_REFILL_LANES: idle lanes at which a wave of the
+  int shadow_refill_lanes = -1;      //   wide-tree kernels stops to supply them
+  long reduce_blocks = -1;           // RTX_REDUCE_BLOCKS: width of the ordered sum of a frame left in flight
+  bool have_overlap_min = false;     // RTX_OVERLAP_MIN_SAMPLES: chunk size from which the sum runs beside the drain kernel
+  unsigned long long overlap_min_samples = 0;
+};
+Hooks read_hooks() {
+  Hooks h;
+  auto flag = [](const char* name) { return std::getenv(name) != nullptr; };
+  auto num = [](const char* name, long none) {
+    const char* e = std::getenv(name);
+    return e ? std::atol(e) : none;
+  };
+  h.no_leaf_tasks = flag("RTX_NO_LEAF_TASKS");
+  h.leaf_tasks_always = flag("RTX_LEAF_TASKS_ALWAYS");
+  h.leaf_task_cap = (int)num("RTX_LEAF_TASK_CAP", 0);
+  h.no_few_triangles = flag("RTX_NO_FEW_TRIANGLES");
+  h.no_lds_scene = flag("RTX_NO_LDS_SCENE");
+  h.queue_light_samples = flag("RTX_QUEUE_LIGHT_SAMPLES");
+  h.no_plain_kernels = flag("RTX_NO_PLAIN_KERNELS");
+  h.few_bounces = num("RTX_FEW_BOUNCES", 2) == 1 ? 1 : 2;
+  h.lds_scene_max_kb = num("RTX_LDS_SCENE_MAX_KB", -1);
+  h.wide_refill_lanes = (int)num("RTX_WIDE_REFILL_LANES", -1);
+  h.shadow_refill_lanes = (int)num("RTX_SHADOW_REFILL_LANES", -1);
+  h.reduce_blocks = num("RTX_REDUCE_BLOCKS", -1);
+  if (const char* e = std::getenv("RTX_OVERLAP_MIN_SAMPLES")) {
+    h.have_overlap_min = true;
+    h.overlap_min_samples = std::strtoull(e, nullptr, 10);
+  }
+  return h;
+}
+
 }  // namespace
 
 struct rtx_ctx {
   rtx_config cfg;
+  Hooks hooks;  // the environment's test hooks as rtx_create found them
   int device = 0;
   uint32_t pool = 0, nseg = 1, cap = 0, finish_paths = kDefaultFinish;
   size_t result_budget_floats = 0;
@@ -364,6 +416,7 @@ static int impl_create(const rtx_config* cfg, rtx_ctx** out) {
   rtx_ctx* c = new (std::nothrow) rtx_ctx();
   if (!c) return fail(RTX_ERR_OUT_OF_MEMORY, "rtx_create: host allocation failed");
   c->cfg = *cfg;
+  c->hooks = read_hooks();
   c->device = dev;
   DeviceGuard g(dev);
   if (!g.ok) {
@@ -432,8 +485,7 @@ static int impl_create(const rtx_config* cfg, rtx_ctx** out) {
   for (int i = 0; i < kPollSlots; i++) CTX_TRY(hipEventCreateWithFlags(&c->poll_ev[i], hipEventDisableTiming));
   CTX_TRY(c->resolve_tmp.alloc(npix * 3));
   CTX_TRY(c->stop4.alloc((npix * 3 + 3) / 4));
-  c->overlap_min_samples = kOverlapMinSamples;
-  if (const char* e = std::getenv("RTX_OVERLAP_MIN_SAMPLES")) c->overlap_min_samples = std::strtoull(e, nullptr, 10);  // (test hook)
+  c->overlap_min_samples = c->hooks.have_overlap_min ? c->hooks.overlap_min_samples : kOverlapMinSamples;
   CTX_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
   CTX_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   CTX_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
@@ -469,8 +521,8 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
   // Larger scenes stream their nodes from L2/HBM: four-child quantised nodes (two levels per
   // 64-byte fetch).  Leaves hold at most 2 triangles in both forms (a box test costs about a
   // third of a triangle test; measured best on the 1M-triangle mesh as well).
-  size_t lds_scene_max = kLdsSceneMaxBytes;
-  if (const char* e = std::getenv("RTX_LDS_SCENE_MAX_KB")) lds_scene_max = (size_t)std::atoi(e) * 1024;  // (tuning runs)
+  const Hooks& hk = c->hooks;
+  const size_t lds_scene_max = hk.lds_scene_max_kb >= 0 ? (size_t)hk.lds_scene_max_kb * 1024 : kLdsSceneMaxBytes;
   const bool small_scene = s->num_triangles > 0 && s->num_triangles * (16 * rtx::kLdsRecordStride * 3 / 2 + 8) <= lds_scene_max;
   rtx::FlatBvh bvh;
   rtx::build_bvh(s->triangles, s->num_triangles, 2u, small_scene ? 2u : 4u, bvh);
@@ -640,7 +692,7 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
   // 0.87; soups of 30 triangles of growing size under the sky: 0.36 -> 1.10, 0.89 -> 0.99, 1.75 -> 0.93, 3.2 -> 0.89,
   // 4.6 -> 0.91.  Where most rays leave the tree after a node or two the list makes them test every leaf box for nothing.
   std::vector<float4> lb;
-  if (bvh.width == 2 && nt < 65536 && !std::getenv("RTX_NO_LEAF_TASKS")) {  // (test hook)
+  if (bvh.width == 2 && nt < 65536 && !hk.no_leaf_tasks) {
     auto half_area = [](float lx, float hx, float ly, float hy, float lz, float hz) {
       const double dx = std::max(0.f, hx - lx), dy = std::max(0.f, hy - ly), dz = std::max(0.f, hz - lz);
       return dx * dy + dy * dz + dz * dx;
@@ -671,7 +723,7 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
         leaf_area += half_area(q1.x, q1.y, q1.z, q1.w, q2.z, q2.w);
       }
     }
-    const bool dense = leaf_area >= kLeafTaskMinLeafArea * root_area || std::getenv("RTX_LEAF_TASKS_ALWAYS");  // (the latter: test hook)
+    const bool dense = leaf_area >= kLeafTaskMinLeafArea * root_area || hk.leaf_tasks_always;
     if (lb.size() > 2 * rtx::kLeafTaskMaxLeaves || !dense) lb.clear();
   }
   HIP_TRY(c->leaf_box.upload(lb));
@@ -695,8 +747,7 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
   d.tri_surf = tm.empty() ? nullptr : c->tri_surf.p;
   d.leaf_box = lb.empty() ? nullptr : c->leaf_box.p;
   d.num_leaf_boxes = (uint32_t)lb.size() / 2;
-  d.leaf_task_cap = 8;
-  if (const char* e = std::getenv("RTX_LEAF_TASK_CAP")) d.leaf_task_cap = (uint32_t)std::min(32, std::max(1, std::atoi(e)));  // (test hook: 1 makes lanes fall back)
+  d.leaf_task_cap = hk.leaf_task_cap > 0 ? (uint32_t)std::min(32, hk.leaf_task_cap) : 8u;  // (1 makes lanes fall back)
   d.sph0 = c->sph0.p; d.sph1 = c->sph1.p; d.sph2 = c->sph2.p; d.sph3 = c->sph3.p;
   d.box0 = c->box0.p; d.box1 = c->box1.p; d.pln0 = c->pln0.p; d.pln1 = c->pln1.p;
   d.num_boxes = (uint32_t)s->num_boxes;
@@ -719,17 +770,24 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
   c->stack_entries = stack_entries;
   c->lds_scene_bytes = (nodes.size() / 4 + nt) * rtx::kLdsRecordStride * sizeof(float4);  // as stage_geom_lds lays it out
   c->wide_refill_lanes = (nodes.size() + (size_t)nt * 4) * sizeof(float4) > kWideLargeTreeBytes ? 32 : 16;
-  if (const char* e = std::getenv("RTX_WIDE_REFILL_LANES")) c->wide_refill_lanes = (uint32_t)std::min(64, std::max(1, std::atoi(e)));  // (tuning hook)
-  if (const char* e = std::getenv("RTX_SHADOW_REFILL_LANES")) c->shadow_refill_lanes = (uint32_t)std::min(64, std::max(0, std::atoi(e)));  // (tuning hook)
+  if (hk.wide_refill_lanes >= 0) c->wide_refill_lanes = (uint32_t)std::min(64, std::max(1, hk.wide_refill_lanes));
+  if (hk.shadow_refill_lanes >= 0) c->shadow_refill_lanes = (uint32_t)std::min(64, hk.shadow_refill_lanes);
   if (bvh.width == 4)
     c->trace_mode = rtx::kGlobalBvh4;
-  else if (nt > 0 && nt <= rtx::kFewTrianglesMax && !std::getenv("RTX_NO_FEW_TRIANGLES"))  // (test hook)
+  else if (nt > 0 && nt <= rtx::kFewTrianglesMax && !hk.no_few_triangles)
     c->trace_mode = rtx::kFewTriangles;
-  else if (nt > 0 && c->lds_scene_bytes <= lds_scene_max && !std::getenv("RTX_NO_LDS_SCENE") &&  // (test hook)
+  else if (nt > 0 && c->lds_scene_bytes <= lds_scene_max && !hk.no_lds_scene &&
            (size_t)stack_entries * kTraceBlock * sizeof(int) + c->lds_scene_bytes <= kLdsLaunchMaxBytes)
     c->trace_mode = rtx::kLdsBvh2;  // (a very deep small tree leaves the LDS to the stacks and stays in global memory)
   else
     c->trace_mode = rtx::kGlobalBvh2;
+  // The kernels that run triangle tests as tasks of the block stage the tree in LDS and put their workspace behind
+  // it: they exist for kLdsBvh2 only.  A tree that ended up elsewhere (a mesh of up to eight triangles, a tree kept in
+  // global memory) has no leaf-box list, whatever its leaves' surfaces add up to.
+  if (c->trace_mode != rtx::kLdsBvh2) {
+    d.leaf_box = nullptr;
+    d.num_leaf_boxes = 0;
+  }
   // (a handful of surfaces and nothing else: hit_surface reads them all through the scalar cache)
   d.few_surfaces = c->trace_mode == rtx::kFewTriangles && s->num_spheres <= 4 && s->num_boxes == 0 && s->num_planes == 0;
   c->have_scene = true;
@@ -823,6 +881,7 @@ int absorb_summary(rtx_ctx* c, uint64_t iterations, uint64_t launches, bool drai
   st.bounces += h.stat_bounces;
   st.nee_samples += h.stat_nee;
   st.shadow_rays += h.stat_shadow;
+  st.stored_paths += h.stat_stored;
   st.nan_paths += h.stat_nan;
   st.truncated_paths += h.stat_truncated;
   st.iterations += iterations;
@@ -880,15 +939,14 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
   // well, as a second round of tasks: no light-sample queue, no launch for it (MIS Cornell 57.4 -> 51.4 ms per
   // frame, same bits).  RTX_QUEUE_LIGHT_SAMPLES keeps the queue and k_shadow_leaf_tasks (test hook).
   const bool inline_light_samples = fused && !few && shadows && c->scene.num_leaf_boxes != 0 &&
-                                    std::getenv("RTX_QUEUE_LIGHT_SAMPLES") == nullptr;
+                                    !c->hooks.queue_light_samples;
   // Light-free scenes without a tree make two bounces per launch (k_trace_shade, BOUNCES); RTX_FEW_BOUNCES=1: one
   // (the hook of the test that compares the two).
-  int few_bounces = 2;
+  const int few_bounces = c->hooks.few_bounces;
   // (a scene of triangles and spheres, path-traced without a bounce limit: kernels built for exactly that)
   const bool plain = c->scene.num_boxes == 0 && c->scene.num_planes == 0 && c->scene.integrator == 0 &&
-                     c->scene.max_bounces == 0 && std::getenv("RTX_NO_PLAIN_KERNELS") == nullptr;
+                     c->scene.max_bounces == 0 && !c->hooks.no_plain_kernels;
   const bool open_sky = c->scene.sky == 1 && c->scene.carries_colour == 0 && c->scene.few_surfaces == 1;
-  if (const char* e = std::getenv("RTX_FEW_BOUNCES")) few_bounces = std::atoi(e) == 1 ? 1 : 2;
   const int fused_block = c->lds_scene_bytes <= kFusedSmallSceneBytes ||
                                   (size_t)c->stack_entries * 256 * sizeof(int) + scene_lds > kLdsLaunchMaxBytes
                               ? 128
@@ -1141,8 +1199,7 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
     // the same order.  RTX_REDUCE_BLOCKS: another width (0: the full one).
     uint32_t blocks = div_up(nfloats, 256);
     if (detach && (nfloats & 3u) == 0) {
-      uint32_t narrow = 64;
-      if (const char* e = std::getenv("RTX_REDUCE_BLOCKS")) narrow = (uint32_t)std::atoi(e);
+      const uint32_t narrow = c->hooks.reduce_blocks >= 0 ? (uint32_t)c->hooks.reduce_blocks : 64u;
       if (narrow != 0) blocks = std::min(blocks, narrow);
     }
     rtx::k_reduce<<<blocks, 256, 0, st>>>(c->res.p, accum_band, nfloats, spp);
@@ -1339,11 +1396,14 @@ static int ensure_twin(rtx_ctx* c) {
     rtx_ctx* t = nullptr;
     if (int rc = impl_create(&cfg, &t)) return rc;
     t->owner = c;
+    t->hooks = c->hooks;
     t->finish_paths = c->finish_paths;
     t->overlap_min_samples = c->overlap_min_samples;
     c->twin = t;
-    if (int rc = events(t)) return rc;
   }
+  // (outside the block: a twin whose stream or events could not be created stays attached, and the next call
+  // tries again instead of enqueuing on a null stream)
+  if (int rc = events(c->twin)) return rc;
   mirror_scene(c);
   // the stacks' spill columns are per launched thread: the second set needs its own
   if (c->spill.n != c->twin->spill.n) HIP_TRY(c->twin->spill.alloc(c->spill.n));
@@ -1590,6 +1650,7 @@ static int impl_get_stats(rtx_ctx* c, rtx_stats* out) {
   if (!c || !out) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_get_stats: null argument");
   if (int rc = wait_frames(c)) return rc;
   *out = c->stats;
+  out->device_allocations = g_device_allocations.load(std::memory_order_relaxed);
   return RTX_OK;
 }
 static int impl_reset_stats(rtx_ctx* c) {
@@ -1610,6 +1671,7 @@ static int impl_accum_alloc(rtx_ctx* c, float** out) {
   DeviceGuard g(c->device);
   if (!g.ok) return fail(RTX_ERR_HIP, "rtx_accum_alloc: hipSetDevice failed");
   size_t bytes = (size_t)c->cfg.width * c->cfg.height * 3 * sizeof(float);
+  g_device_allocations.fetch_add(1, std::memory_order_relaxed);
   HIP_TRY(hipMalloc((void**)out, bytes));
   HIP_TRY(hipMemset(*out, 0, bytes));
   return RTX_OK;

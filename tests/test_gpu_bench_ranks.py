@@ -40,6 +40,20 @@ def test_bench_starts_its_own_ranks(rtx_lib):
     assert two["value"] > 0 and two["cpu_baseline"] is None
 
 
+def test_default_bench_line_carries_time_to_image_and_a_strong_leg(rtx_lib):
+    """The default workload's line: with one rank a numeric time_to_image_ms (frames rendered and waited for
+    one at a time); with two ranks (both on the one GPU, gloo) the weak value plus a `strong` leg in which the
+    256 spp are split over the ranks and summed per frame."""
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu", "--no-profile"]
+    env = dict(os.environ, RTX_BENCH_SAME_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    two = run_bench(*common, "--gpus", "2", "--backend", "gloo", env=env)
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak"
+    assert two["strong"]["spp_per_gpu"] == 128 and two["strong"]["time_to_image_ms"] > 0
+    assert two["time_to_image_ms"] == two["strong"]["time_to_image_ms"]
+    assert two["time_to_image"]["frames"]["n"] == 5
+
+
 def test_exchange_step_with_one_rank_through_the_binding(rtx_lib):
     """rtx_comm_create_id / init / reduce / destroy with a communicator of one rank: the reduce is
     stream-ordered behind the render and leaves the root's sums as they are."""

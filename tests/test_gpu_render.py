@@ -205,7 +205,10 @@ def test_triangle_tests_as_tasks_of_the_block_keep_the_bits(cap, rtx_lib, monkey
     one triangle, overlapping triangles with equal t, spheres in front of the mesh), RTX_LEAF_TASK_CAP shrinks the
     queue until lanes have to test their leaves themselves: same images, same counts."""
     cases = [(scenes.cornell(), 0), (scenes.cornell(lights=4), 0), (scenes.soup(30, 3, seed=2, size=0.5), 1),
-             (scenes.soup(57, 0, seed=9, size=0.9), 1), (scenes.soup(9, 2, seed=4, size=0.9), 1)]
+             (scenes.soup(57, 0, seed=9, size=0.9), 1), (scenes.soup(9, 2, seed=4, size=0.9), 1),
+             # lit meshes of up to eight triangles are tested without a tree: they must not get the task kernels
+             # (whose workspace sits behind a tree staged in LDS), whatever the hook asks for
+             (scenes.soup(8, 1, seed=6, size=0.9), 0), (scenes.soup(6, 0, seed=3, size=0.9), 1)]
     for sc, sky in cases:
         for kw in (dict(width=200, height=120, sky=sky, pool_paths=1 << 13),
                    dict(width=97, height=61, sky=sky, pool_paths=700, max_bounces=4, camera=2)):

@@ -1,8 +1,9 @@
 """GPU test of rtx_trace_closest_noalloc, the entry point that allocates nothing: its results
 against rtx_trace_closest's, bit for bit (kind, primitive, t, normal), on two calls in a row,
 the second with fewer rays (the staging array keeps the first call's contents), for every
-traversal mode (LDS two-child tree, global four-child tree, analytic objects only), and the
-size limit."""
+traversal mode (LDS two-child tree, global four-child tree, analytic objects only), the
+size limit, and the property itself: the library's count of hipMalloc calls
+(rtx_stats.device_allocations) does not move across a call."""
 import numpy as np
 import pytest
 
@@ -29,12 +30,19 @@ def test_noalloc_matches_trace_closest_twice(make, rtx_lib):
         big = scenes.random_rays(MAX_RAYS, seed=11)       # the maximum size; several launches (pool < n)
         small = scenes.random_rays(5000, seed=12)          # then a smaller call on the same staging array
         for rays in (big, small):
+            before = r.stats().device_allocations
             want = r.trace_closest(rays)
+            mid = r.stats().device_allocations
             got = r.trace_closest(rays, noalloc=True)
+            # the property itself: the allocating entry point made hipMalloc calls (the counter is live),
+            # the other one made none
+            assert mid > before and r.stats().device_allocations == mid
             same_bits(got, want)
             assert (want[0] != 0).any()
         # without normals
+        mid = r.stats().device_allocations
         got = r.trace_closest(small, want_normal=False, noalloc=True)
+        assert r.stats().device_allocations == mid
         want = r.trace_closest(small, want_normal=False)
         same_bits(got[:3], want[:3])
         assert got[3] is None

@@ -25,6 +25,8 @@ Q2=$(find $OUT/sq2 -name '*counter_collection.csv' | head -n 1)
 python3 tools/pmc_sq.py $W $OUT/sq_counters_$W.json $OUT/sq_counters_$W.txt $Q1 $Q2 > /dev/null
 S=$(find $OUT/stats -name '*kernel_stats.csv' | head -n 1)
 cp $S $OUT/kernel_stats.csv
+# what the counters were collected from: the hash bench.py compares with the tree (profiles_stale)
+python3 -c "import bench; print(bench.csrc_sha256())" > $OUT/csrc_sha256.txt
 # the raw counter CSVs are large; keep only the summaries
 rm -rf $OUT/fetch $OUT/write $OUT/stats $OUT/sq1 $OUT/sq2
 ls -la $OUT
