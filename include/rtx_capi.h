@@ -321,6 +321,7 @@ int rtx_accum_upload(rtx_ctx* ctx, float* accum_dev, const float* sums_host, voi
  *   RTX_LDS_SCENE_MAX_KB=n   size up to which a tree is staged in LDS (default 24)
  *   RTX_NO_PLAIN_KERNELS     the general build of the bounce and drain kernels for every scene
  *   RTX_FEW_BOUNCES=1        one bounce per launch where two are the default
+ *   RTX_NO_LEAF_PAIRS        large meshes: one record per triangle where the halves of a quad share one by default
  *   RTX_WIDE_REFILL_LANES=n, RTX_SHADOW_REFILL_LANES=n
  *                            idle lanes at which a wave of the wide-tree kernels takes new rays
  *   RTX_REDUCE_BLOCKS=n      width of the ordered sum of a frame left in flight (0: full width)

@@ -615,6 +615,41 @@ __device__ __forceinline__ void any_leaves(const Geom& g, const Stack& stk, floa
   }
 }
 
+// Leaf pairs of the wide tree.  The reference fan-tessellates polygons (Scene.h:55-115), so the two halves of a quad
+// arrive as consecutive triangles (a, b, c), (a, c, d), and a builder with leaves of two puts most such halves into
+// one leaf (98 % of the leaves of a 1 M-triangle height field).  Such a leaf is one 64-byte record of its four
+// vertices and two primitive ids instead of two records of a triangle each (kLeafPairFlag in the leaf word): the walk
+// on the wide tree is bound by the record fetches that miss the L2, and half of those are triangles.  The edges and
+// normals the single record stores are computed here instead, with the float operations the host uses for it
+// (b + (-a), the cross product without contraction): a hit has the same bits either way.
+//   row 0 (a.xyz, primitive id of (a, b, c))   row 1 (b.xyz, primitive id of (a, c, d))   row 2 (c.xyz, 0)   row 3 (d.xyz, 0)
+constexpr uint32_t kLeafPairFlag = 4u;  // in the low three bits of a leaf word, beside count - 1 = 1
+struct PairHit {
+  float t0, t1;  // Triangle::intersect of each half (Obj.h:110-121); INFINITY: rejected
+};
+__device__ __forceinline__ PairHit pair_intersect(float4 q0, float4 q1, float4 q2, float4 q3, f3 o, f3 d) {
+  const f3 a = mk3(q0.x, q0.y, q0.z);
+  const f3 ba = vsub(mk3(q1.x, q1.y, q1.z), a), ca = vsub(mk3(q2.x, q2.y, q2.z), a), da = vsub(mk3(q3.x, q3.y, q3.z), a);
+  const f3 roa = vsub(o, a);
+  const f3 q = vcross(roa, d);
+  PairHit h;
+  {
+    const f3 n = vcross(ba, ca);
+    const float inv = 1.0f / vdot(d, n);
+    const float u = inv * -vdot(q, ca);
+    const float v = inv * vdot(q, ba);
+    h.t0 = (u < 0.0f || u > 1.0f || v < 0.0f || (u + v) > 1.0f) ? INFINITY : inv * -vdot(n, roa);
+  }
+  {
+    const f3 n = vcross(ca, da);
+    const float inv = 1.0f / vdot(d, n);
+    const float u = inv * -vdot(q, da);
+    const float v = inv * vdot(q, ca);
+    h.t1 = (u < 0.0f || u > 1.0f || v < 0.0f || (u + v) > 1.0f) ? INFINITY : inv * -vdot(n, roa);
+  }
+  return h;
+}
+
 // Single-phase walk for the wide tree in global memory, where every step waits on a
 // fetch: nodes and triangles are both 64-byte records, so each iteration fetches
 // the one record its lane stands on, whichever kind, and all lanes wait once.  A
@@ -664,15 +699,31 @@ __device__ __forceinline__ void closest_step(const Geom& g, const Stack& stk, fl
       }
     } else {
       const uint32_t leaf = ~(uint32_t)w.cur;
-      const float t = tri_intersect_n(mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q2.x, q2.y, q2.z),
-                                      mk3(q3.x, q3.y, q3.z), w.o, w.d);
-      const uint32_t prim = __float_as_uint(q0.w);
-      if (eps < t && t < INFINITY && (t < best.t || (t == best.t && prim < best.prim))) {
-        best.t = t;
-        best.prim = prim;
-        best.slot = leaf >> 3;
+      if (leaf & kLeafPairFlag) {  // both halves of a quad from one record, in slot order
+        const PairHit h = pair_intersect(q0, q1, q2, q3, w.o, w.d);
+        const uint32_t p0 = __float_as_uint(q0.w), p1 = __float_as_uint(q1.w);
+        if (eps < h.t0 && h.t0 < INFINITY && (h.t0 < best.t || (h.t0 == best.t && p0 < best.prim))) {
+          best.t = h.t0;
+          best.prim = p0;
+          best.slot = leaf >> 3;
+        }
+        if (eps < h.t1 && h.t1 < INFINITY && (h.t1 < best.t || (h.t1 == best.t && p1 < best.prim))) {
+          best.t = h.t1;
+          best.prim = p1;
+          best.slot = (leaf >> 3) + 1u;
+        }
+        w.cur = w.sp == 0 ? (int)kTraversalDone : stk.pop(w.sp);
+      } else {
+        const float t = tri_intersect_n(mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q2.x, q2.y, q2.z),
+                                        mk3(q3.x, q3.y, q3.z), w.o, w.d);
+        const uint32_t prim = __float_as_uint(q0.w);
+        if (eps < t && t < INFINITY && (t < best.t || (t == best.t && prim < best.prim))) {
+          best.t = t;
+          best.prim = prim;
+          best.slot = leaf >> 3;
+        }
+        w.cur = after_triangle(leaf, stk, w.sp);
       }
-      w.cur = after_triangle(leaf, stk, w.sp);
     }
   }
 }
@@ -705,13 +756,19 @@ __device__ __forceinline__ void any_step(const Geom& g, const Stack& stk, float 
       w.cur = next != kTraversalDone ? next : (w.sp == 0 ? kTraversalDone : stk.pop(w.sp));
     } else {
       const uint32_t leaf = ~(uint32_t)w.cur;
-      const float t = tri_intersect_n(mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q2.x, q2.y, q2.z),
-                                      mk3(q3.x, q3.y, q3.z), w.o, w.d);
-      hit = eps < t && t < tfar;
-      if (hit)
-        w.cur = kTraversalDone;
-      else
-        w.cur = after_triangle(leaf, stk, w.sp);
+      if (leaf & kLeafPairFlag) {
+        const PairHit h = pair_intersect(q0, q1, q2, q3, w.o, w.d);
+        hit = (eps < h.t0 && h.t0 < tfar) || (eps < h.t1 && h.t1 < tfar);
+        w.cur = (hit || w.sp == 0) ? (int)kTraversalDone : stk.pop(w.sp);
+      } else {
+        const float t = tri_intersect_n(mk3(q0.x, q0.y, q0.z), mk3(q1.x, q1.y, q1.z), mk3(q2.x, q2.y, q2.z),
+                                        mk3(q3.x, q3.y, q3.z), w.o, w.d);
+        hit = eps < t && t < tfar;
+        if (hit)
+          w.cur = kTraversalDone;
+        else
+          w.cur = after_triangle(leaf, stk, w.sp);
+      }
     }
   }
 }
@@ -1631,6 +1688,13 @@ __global__ __launch_bounds__(BLOCK, MODE == kGlobalBvh2 ? 4 : 8) void k_intersec
 
 constexpr uint32_t kNoRay = 0xffffffffu;
 
+#ifdef RTX_WALK_STATS
+// Diagnostic build only (make EXTRA=-DRTX_WALK_STATS): what the waves of k_intersect_wide do, summed over the
+// launches since the last read.  [0] wave iterations, [1] lanes at a node, [2] lanes at a triangle, summed over the
+// iterations, [3] iterations with both kinds, [4] with nodes only, [5] with triangles only, [6] refill stops, [7] rays.
+__device__ unsigned long long g_walk_stats[8];
+#endif
+
 // k_intersect for the wide tree in global memory.  In the single-phase walk a lane whose ray has
 // ended would only idle until the longest ray of the wave ends (4 of 5 lanes on the 1 M-triangle
 // mesh), so a wave keeps its lanes supplied instead: the waves of a segment take its rays 64 at a
@@ -1683,11 +1747,17 @@ __global__ __launch_bounds__(BLOCK, RTX_WIDE_OCC) void k_intersect_wide(SceneDev
   w.sp = 0;
   ClosestHit best = {INFINITY, kMiss, kMiss};
   uint32_t ri = kNoRay, object_id = kMiss;
+#ifdef RTX_WALK_STATS
+  unsigned long long ws_it = 0, ws_node = 0, ws_leaf = 0, ws_both = 0, ws_nonly = 0, ws_lonly = 0, ws_refill = 0;
+#endif
   for (;;) {
     const bool walking = w.cur != kTraversalDone;
     const unsigned long long wm = __ballot(walking);
     const uint32_t idle = 64u - (uint32_t)__popcll(wm);
     if (wm == 0 || (idle >= refill_lanes && cb + used < ce)) {  // wave-uniform
+#ifdef RTX_WALK_STATS
+      ws_refill++;
+#endif
       const unsigned long long im = ~wm;
       const uint32_t rank =
           __builtin_amdgcn_mbcnt_hi((uint32_t)(im >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)im, 0u));
@@ -1722,8 +1792,31 @@ __global__ __launch_bounds__(BLOCK, RTX_WIDE_OCC) void k_intersect_wide(SceneDev
       }
       if (cb >= n && __ballot(ri != kNoRay) == 0) break;
     }
+#ifdef RTX_WALK_STATS
+    {
+      const unsigned long long nm = __ballot(w.cur != kTraversalDone && w.cur >= 0);
+      const unsigned long long lm = __ballot(w.cur != kTraversalDone && w.cur < 0);
+      ws_it++;
+      ws_node += __popcll(nm);
+      ws_leaf += __popcll(lm);
+      ws_both += (nm != 0 && lm != 0);
+      ws_nonly += (nm != 0 && lm == 0);
+      ws_lonly += (nm == 0 && lm != 0);
+    }
+#endif
     if (w.cur != kTraversalDone) closest_step(geom, stk, sc.eps, w, best);
   }
+#ifdef RTX_WALK_STATS
+  if (lane == 0) {
+    atomicAdd(&g_walk_stats[0], ws_it);
+    atomicAdd(&g_walk_stats[1], ws_node);
+    atomicAdd(&g_walk_stats[2], ws_leaf);
+    atomicAdd(&g_walk_stats[3], ws_both);
+    atomicAdd(&g_walk_stats[4], ws_nonly);
+    atomicAdd(&g_walk_stats[5], ws_lonly);
+    atomicAdd(&g_walk_stats[6], ws_refill);
+  }
+#endif
 }
 
 // Block-level append: one atomic per block reserves the slots of all its waves, so the

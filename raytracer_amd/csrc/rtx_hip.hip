@@ -210,6 +210,7 @@ struct Hooks {
   long lds_scene_max_kb = -1;        // RTX_LDS_SCENE_MAX_KB: size up to which a tree is staged in LDS
   int wide_refill_lanes = -1;        // RTX_WIDE_REFILL_LANES, RTX_SHADOW_REFILL_LANES: idle lanes at which a wave of the
   int shadow_refill_lanes = -1;      //   wide-tree kernels stops to supply them
+  bool no_leaf_pairs = false;        // RTX_NO_LEAF_PAIRS: wide tree: the two halves of a quad as two records
   long reduce_blocks = -1;           // RTX_REDUCE_BLOCKS: width of the ordered sum of a frame left in flight
   bool have_overlap_min = false;     // RTX_OVERLAP_MIN_SAMPLES: chunk size from which the sum runs beside the drain kernel
   unsigned long long overlap_min_samples = 0;
@@ -232,6 +233,7 @@ Hooks read_hooks() {
   h.lds_scene_max_kb = num("RTX_LDS_SCENE_MAX_KB", -1);
   h.wide_refill_lanes = (int)num("RTX_WIDE_REFILL_LANES", -1);
   h.shadow_refill_lanes = (int)num("RTX_SHADOW_REFILL_LANES", -1);
+  h.no_leaf_pairs = flag("RTX_NO_LEAF_PAIRS");
   h.reduce_blocks = num("RTX_REDUCE_BLOCKS", -1);
   if (const char* e = std::getenv("RTX_OVERLAP_MIN_SAMPLES")) {
     h.have_overlap_min = true;
@@ -579,6 +581,34 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
     // perform per hit, done once here (this file is compiled without contraction as well).
     const float len = std::sqrt(nx * nx + ny * ny + nz * nz);
     tn[slot] = make_float4(nx / len, ny / len, nz / len, fmi);
+  }
+  // Wide tree: a leaf whose two triangles are the halves of a fan-tessellated quad, (a, b, c) then (a, c, d) bit for
+  // bit, becomes one record of the four vertices (rtx::pair_intersect); its leaf word gets kLeafPairFlag.  The record
+  // of the second slot stays as it is (nothing fetches it during a walk; its primitive id is still looked up there).
+  if (bvh.width == 4 && !hk.no_leaf_pairs) {
+    for (size_t k = 3; k < nodes.size(); k += 4) {
+      int refs[4];
+      std::memcpy(refs, &nodes[k], 16);
+      for (int& r : refs) {
+        if (r >= 0 || r == rtx::kTraversalDone) continue;
+        const uint32_t leaf = ~(uint32_t)r;
+        if ((leaf & 7u) != 1u) continue;  // leaves of exactly two
+        const uint32_t first = leaf >> 3;
+        const uint32_t p0 = bvh.order[first], p1 = bvh.order[first + 1];
+        const float* t0 = s->triangles + 9 * (size_t)p0;
+        const float* t1 = s->triangles + 9 * (size_t)p1;
+        if (std::memcmp(t1, t0, 12) != 0 || std::memcmp(t1 + 3, t0 + 6, 12) != 0) continue;
+        float f0, f1;
+        std::memcpy(&f0, &p0, 4);
+        std::memcpy(&f1, &p1, 4);
+        tr[4 * (size_t)first] = make_float4(t0[0], t0[1], t0[2], f0);
+        tr[4 * (size_t)first + 1] = make_float4(t0[3], t0[4], t0[5], f1);
+        tr[4 * (size_t)first + 2] = make_float4(t0[6], t0[7], t0[8], 0.f);
+        tr[4 * (size_t)first + 3] = make_float4(t1[6], t1[7], t1[8], 0.f);
+        r = (int)~(leaf | rtx::kLeafPairFlag);
+      }
+      std::memcpy(&nodes[k], refs, 16);
+    }
   }
   std::vector<float4> m0(s->num_materials);
   std::vector<int> m1(s->num_materials);
@@ -1704,6 +1734,16 @@ static int impl_accum_upload(rtx_ctx* c, float* p, const float* sums_host, void*
 }
 
 }  // extern "C"
+
+#ifdef RTX_WALK_STATS
+// Diagnostic build only: reads and clears the counters of k_intersect_wide's waves (kernels.h, g_walk_stats).
+extern "C" int rtx_debug_walk_stats(unsigned long long out[8]) {
+  unsigned long long zero[8] = {};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rtx::g_walk_stats), sizeof(zero)) != hipSuccess) return RTX_ERR_HIP;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(rtx::g_walk_stats), zero, sizeof(zero)) != hipSuccess) return RTX_ERR_HIP;
+  return RTX_OK;
+}
+#endif
 
 // The exported entry points: nothing thrown inside the library (std::bad_alloc from a vector,
 // std::system_error from a worker thread) crosses the C boundary; it becomes a status code.

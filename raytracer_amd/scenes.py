@@ -276,6 +276,33 @@ def soup(ntri=10000, nsph=3, seed=1, extent=1.0, size=0.15) -> SceneData:
                      name=f"soup_{ntri}")
 
 
+def quad_soup(nquad=2500, seed=1, extent=1.0, size=0.2) -> SceneData:
+    """Random quadrilaterals as the reference's fan tessellation leaves them (Scene.h:55-115): consecutive
+    triangles (a, b, c), (a, c, d) -- planar, folded and self-crossing ones, every tenth quad twice (hits at equal t),
+    every seventh with its second half's vertices rotated to (c, d, a) (the same triangle, not the fan's order) and
+    every eleventh with the halves swapped in the triangle order."""
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-extent, extent, (nquad, 1, 3)) + np.array([0.0, 1.0, 0.0])
+    v = (c + rng.uniform(-size, size, (nquad, 4, 3))).astype(np.float32)
+    planar = rng.random(nquad) < 0.5     # d = a + (c - b): a parallelogram
+    v[planar, 3] = (v[planar, 0] + (v[planar, 2] - v[planar, 1])).astype(np.float32)
+    tris = []
+    for k in range(nquad):
+        a, b, cc, d = v[k]
+        t0, t1 = np.concatenate([a, b, cc]), np.concatenate([a, cc, d])
+        if k % 7 == 3:
+            t1 = np.concatenate([cc, d, a])
+        pair = [t1, t0] if k % 11 == 5 else [t0, t1]
+        tris += pair
+        if k % 10 == 0:
+            tris += pair
+    t = np.array(tris, np.float32)
+    mats = np.array([material(WHITE), material(RED), material(GREEN, 0.0, REFLECTIVE),
+                     material((1, 1, 1), 0.0, SPECULAR), material((0.8, 0.8, 0.8), 4.0)], MATERIAL_DTYPE)
+    mi = rng.integers(0, len(mats), len(t)).astype(np.uint32)
+    return SceneData(t, mi, mats, name=f"quad_soup_{nquad}")
+
+
 def random_rays(n, seed=7, origin_box=((-1.2, -0.2, -1.2), (1.2, 2.2, 3.2)), unit=True) -> np.ndarray:
     """n rays (o, d) with origins uniform in a box and directions uniform on the sphere."""
     rng = np.random.default_rng(seed)

@@ -234,6 +234,24 @@ def test_triangle_tests_as_tasks_of_the_block_keep_the_bits(cap, rtx_lib, monkey
     monkeypatch.delenv("RTX_LEAF_TASK_CAP", raising=False)
 
 
+def test_leaf_pairs_of_the_wide_tree_keep_the_bits(rtx_lib, monkeypatch):
+    """On the wide tree a leaf that holds the two halves of a fan-tessellated quad is one record of four vertices
+    (edges and normals computed in the walk); RTX_NO_LEAF_PAIRS=1 keeps one record per triangle with the normal
+    stored.  Same images, same counts, for the closest-hit walk, the light samples and the drain kernel."""
+    cases = [(scenes.terrain(40), 0), (scenes.quad_soup(1500, seed=3), 1), (scenes.quad_soup(400, seed=9, size=0.6), 0)]
+    for sc, sky in cases:
+        for kw in (dict(width=160, height=100, sky=sky, pool_paths=1 << 13),
+                   dict(width=97, height=61, sky=sky, pool_paths=900, max_bounces=5, camera=1, finish_paths=1 << 20)):
+            monkeypatch.setenv("RTX_NO_LEAF_PAIRS", "1")
+            a, sa, ia = gpu_render(Config(**kw), sc, 5)
+            monkeypatch.delenv("RTX_NO_LEAF_PAIRS")
+            b, sb, _ = gpu_render(Config(**kw), sc, 5)
+            assert ia.bvh_width == 4
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (sc.name, kw)
+            assert (sa.paths, sa.bounces, sa.nee_samples, sa.shadow_rays, sa.nan_paths) == \
+                   (sb.paths, sb.bounces, sb.nee_samples, sb.shadow_rays, sb.nan_paths), (sc.name, kw)
+
+
 def test_scenes_without_emitters_skip_the_colour_state_and_keep_their_bits(oracle, rtx_lib):
     """Where no material emits and there are no lights a live path's colour is exactly 0, and the queues
     do not carry it.  An emissive material that no surface uses switches the skipping off: same image."""

@@ -39,6 +39,9 @@ SCENES = {
     "cornell_4lights": lambda: scenes.cornell(lights=4),
     "sphere_sky": lambda: scenes.sphere_sky(),
     "soup10k": lambda: scenes.soup(10000, 3),
+    # the wide tree's leaves of a fan-tessellated quad as one record of four vertices, beside leaves that do not qualify
+    "quad_soup": lambda: scenes.quad_soup(2500, seed=4),
+    "terrain40": lambda: scenes.terrain(40),
     "one_triangle": lambda: scenes.SceneData(scenes.quad((-1, 0, 0), (1, 0, 0), (1, 2, 0), (-1, 2, 0))[:1],
                                              np.zeros(1, np.uint32),
                                              np.array([scenes.material(scenes.WHITE)], scenes.MATERIAL_DTYPE)),
@@ -257,7 +260,8 @@ def test_triangles_that_share_a_vertex_or_a_plane(oracle, rtx_lib):
             assert (want[0] != 0).sum() > 2000, name
 
 
-@pytest.mark.parametrize("name", ["cornell", "soup10k", "sphere_sky", "spheres_only", "ref_scene0", "ref_scene1"])
+@pytest.mark.parametrize("name", ["cornell", "soup10k", "quad_soup", "terrain40", "sphere_sky", "spheres_only", "ref_scene0",
+                                  "ref_scene1"])
 def test_occlusion_bit_exact(name, oracle, rtx_lib):
     cfg = Config(width=800, height=800, pool_paths=1 << 16)
     sc = SCENES[name]()

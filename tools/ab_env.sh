@@ -6,7 +6,7 @@ W=$1; shift
 for E in "$@"; do
   for rep in 1 2; do
   ( if [ "$E" != "-" ]; then IFS=, ; for kv in $E; do export "$kv"; done; unset IFS; fi
-    timeout -k 10 200 python bench.py --workload $W --no-cpu --no-mis > gpurun_out/ab_tmp.json 2>gpurun_out/ab_err.txt ) || { echo "$E failed"; tail -3 gpurun_out/ab_err.txt; exit 1; }
+    timeout -k 10 200 python bench.py --workload $W --no-cpu --no-legs > gpurun_out/ab_tmp.json 2>gpurun_out/ab_err.txt ) || { echo "$E failed"; tail -3 gpurun_out/ab_err.txt; exit 1; }
   python - "$E" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/ab_tmp.json"))

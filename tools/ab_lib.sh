@@ -7,7 +7,7 @@ for W in "$@"; do
   for rep in 1 2 3; do
     for L in new old; do
       ( if [ $L = old ]; then export RTX_LIB=$OLD; fi
-        timeout -k 10 200 python bench.py --workload $W --no-cpu --no-mis > gpurun_out/ab_tmp.json 2>gpurun_out/ab_err.txt ) || { echo "$L failed"; tail -3 gpurun_out/ab_err.txt; exit 1; }
+        timeout -k 10 200 python bench.py --workload $W --no-cpu --no-legs > gpurun_out/ab_tmp.json 2>gpurun_out/ab_err.txt ) || { echo "$L failed"; tail -3 gpurun_out/ab_err.txt; exit 1; }
       python - "$L $W" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/ab_tmp.json"))

@@ -6,7 +6,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/kt_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o s -- python3 $REPO/bench.py --no-cpu --no-mis --no-profile "$@" > /dev/null 2> $OUT/err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o s -- python3 $REPO/bench.py --no-cpu --no-legs --no-profile "$@" > /dev/null 2> $OUT/err
 cd $REPO
 python3 - $OUT <<'PY'
 import csv, glob, sys

@@ -6,7 +6,7 @@
 set -e
 for W in sample3_mis_cornell soup100 soup150 soup220 soup300 soup380; do
   for KB in 48 0; do
-    RTX_LDS_SCENE_MAX_KB=$KB timeout -k 10 200 python bench.py --workload $W --no-cpu --no-mis > gpurun_out/lg_tmp.json 2>/dev/null
+    RTX_LDS_SCENE_MAX_KB=$KB timeout -k 10 200 python bench.py --workload $W --no-cpu --no-legs > gpurun_out/lg_tmp.json 2>/dev/null
     python - "$W" "$KB" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/lg_tmp.json"))

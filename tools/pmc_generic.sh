@@ -7,7 +7,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/pmc_$W
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 300 rocprofv3 --pmc $CTRS --output-format csv -d $OUT/raw -o q -- python3 $REPO/bench.py --workload $W --steps 1 --warmup 0 --no-cpu --no-mis --no-profile "$@" > /dev/null 2> $OUT/err
+timeout -s KILL 300 rocprofv3 --pmc $CTRS --output-format csv -d $OUT/raw -o q -- python3 $REPO/bench.py --workload $W --steps 1 --warmup 0 --no-cpu --no-legs --no-profile "$@" > /dev/null 2> $OUT/err
 cd $REPO
 python3 - $OUT <<'PY'
 import csv, sys, glob, collections

@@ -6,7 +6,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/insts_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="$REPO/bench.py --workload $W --no-cpu --no-mis --steps 1 --warmup 0 --no-profile"
+B="$REPO/bench.py --workload $W --no-cpu --no-legs --steps 1 --warmup 0 --no-profile"
 timeout -s KILL 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d $OUT/p1 -o q -- python3 $B "$@" > /dev/null 2> $OUT/p1.err || { tail -5 $OUT/p1.err; exit 1; }
 cd $REPO
 python3 - $OUT <<'PY'

@@ -7,7 +7,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/lat_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="$REPO/bench.py --workload $W --no-cpu --no-mis --steps 1 --warmup 0 --no-profile"
+B="$REPO/bench.py --workload $W --no-cpu --no-legs --steps 1 --warmup 0 --no-profile"
 i=0
 for P in "MeanOccupancyPerCU VmemLatency" "SmemLatency InstrFetchLatency" "LdsLatency VALUBusy"; do
   i=$((i+1))

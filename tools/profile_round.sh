@@ -10,7 +10,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="$REPO/bench.py --workload $W --no-cpu --no-mis"
+B="$REPO/bench.py --workload $W --no-cpu --no-legs"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python3 $B --steps 2 --warmup 1 "$@" > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o f -- python3 $B --steps 1 --warmup 0 --no-profile "$@" > /dev/null 2> $OUT/fetch.err
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o w -- python3 $B --steps 1 --warmup 0 --no-profile "$@" > /dev/null 2> $OUT/write.err

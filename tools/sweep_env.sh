@@ -5,7 +5,7 @@ VAR=$1; VALS=$2; shift 2
 for W in "$@"; do
   for V in $VALS; do
     export $VAR=$V
-    timeout -k 10 200 python bench.py --workload $W --no-cpu --no-mis > gpurun_out/ab_tmp.json 2>gpurun_out/ab_err.txt || { tail -3 gpurun_out/ab_err.txt; exit 1; }
+    timeout -k 10 200 python bench.py --workload $W --no-cpu --no-legs > gpurun_out/ab_tmp.json 2>gpurun_out/ab_err.txt || { tail -3 gpurun_out/ab_err.txt; exit 1; }
     python - "$W" $VAR=$V <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/ab_tmp.json"))
