@@ -112,6 +112,16 @@ typedef struct {
                             where the tree is small enough to be staged in LDS: the search then costs less
                             than passing the ray and the hit through memory; two kernels otherwise),
                             1 = always two kernels, 2 = as 0 today.  All give the same bits. */
+  int32_t rng_streams;   /* 0 = the reference's generator, bit for bit: 32 bits of state on ONE cycle of 2^32 values
+                            (Sampler.h:11-42), every sample a starting point on that cycle -- 2^32 distinct starting
+                            points in all, so a render of more than 2^32 samples (3840x2160 at 4096 per pixel is
+                            3.4e10) repeats samples, and long paths of different samples share stretches of the
+                            cycle.  1 = the same generator with an odd increment of its own per sample: state and
+                            increment are the two halves of a 64-bit bijective mix of (sample index, pixel, seed), so
+                            that the samples of such a render start from distinct (state, increment) pairs (about
+                            31 coinciding pairs expected among 3.4e10), each on its own cycle.  Same estimator, other
+                            random numbers: images agree with mode 0 in distribution, not bit for bit.  No counterpart
+                            in the reference.  Costs 4 bytes more per stored path and the kernels' general build. */
 } rtx_config;
 
 /* Scene geometry, borrowed for the duration of rtx_set_scene.
@@ -204,7 +214,8 @@ int rtx_get_scene_info(rtx_ctx* ctx, rtx_scene_info* out);
  * of state on one cycle of 2^32 values.  The seed is folded to 32 bits (low word xor high word)
  * and a path starts at state pcg_hash(pixel ^ pcg_hash(sample ^ pcg_hash(seed32))): there are 2^32
  * distinct starting points in all, paths are shifted copies of one sequence (as the reference's
- * eight per-thread generators are), and a render of more than 2^32 samples repeats samples.  Returns after the work has finished on `stream`
+ * eight per-thread generators are), and a render of more than 2^32 samples repeats samples
+ * (rtx_config.rng_streams = 1 lifts that limit).  Returns after the work has finished on `stream`
  * (it polls the path queue's length while it drains). */
 int rtx_render(rtx_ctx* ctx, float* accum_dev, uint32_t spp, uint32_t sample_base, uint64_t seed,
                const float cam_offset[3], uint32_t row0, uint32_t row1, void* stream);
@@ -284,6 +295,14 @@ int rtx_stream_synchronize(rtx_ctx* ctx, void* stream);
  * each computed by the device functions the render kernels use.  n <= 2^20.  Synchronous. */
 int rtx_debug_pcg(rtx_ctx* ctx, uint32_t seed, uint32_t n, uint32_t* rand_out, float* uniform_out,
                   uint32_t* hash_out);
+
+/* The generator each sample of a call rtx_render(spp, sample_base, seed) over all rows starts with, as the render
+ * kernels set it up: out_dev[k] = state | increment << 32 for sample sample_base + k / (width*height) of pixel
+ * k mod (width*height); out_dev is a device array of width*height*spp 64-bit words.  With rng_streams = 0 the
+ * increment is the reference's constant 2891336453 (Sampler.h:26).  Enqueues on `stream`.  For tests of
+ * rtx_config.rng_streams; no counterpart in the reference. */
+int rtx_debug_streams(rtx_ctx* ctx, uint32_t spp, uint32_t sample_base, uint64_t seed, uint64_t* out_dev,
+                      void* stream);
 
 /* Counters since rtx_create or the last rtx_reset_stats. */
 int rtx_get_stats(rtx_ctx* ctx, rtx_stats* out);

@@ -43,6 +43,7 @@ class OConfig(C.Structure):
         ("camera", C.c_int32), ("integrator", C.c_int32),
         ("focal_length", C.c_float), ("lens_radius", C.c_float),
         ("stretch_x", C.c_float), ("stretch_y", C.c_float),
+        ("rng_streams", C.c_int32),
     ]
 
 
@@ -188,7 +189,13 @@ def config_from(cfg) -> OConfig:
     o.sky, o.max_bounces, o.camera, o.integrator = cfg.sky, cfg.max_bounces, cfg.camera, cfg.integrator
     o.focal_length, o.lens_radius = cfg.focal_length, cfg.lens_radius
     o.stretch_x, o.stretch_y = cfg.stretch_x, cfg.stretch_y
+    o.rng_streams = getattr(cfg, "rng_streams", 0)
     return o
+
+
+def path_seed(pixel_index: int, sample_index: int, seed: int = 0x5EED) -> int:
+    """The starting state of a sample's generator (the build's counter-based seeding)."""
+    return int(lib().orc_path_seed(pixel_index, sample_index, seed))
 
 
 def pcg_rand(seed: int, n: int, which=None):

@@ -73,9 +73,10 @@ const double kPi = 3.14159265358979323846;  // M_PI
 // Sampler.h:11-42.  32-bit-state PCG (RXS-M-XS output of the OLD state).
 struct Rng {
   uint32_t s;
+  uint32_t inc = 2891336453u;  // the reference's constant; orc_config.rng_streams gives every sample its own (stream_rng)
   uint32_t next() {  // rand_pcg, Sampler.h:24-30
     uint32_t old = s;
-    s = s * 747796405u + 2891336453u;
+    s = s * 747796405u + inc;
     uint32_t w = ((old >> ((old >> 28u) + 4u)) ^ old) * 277803737u;
     return (w >> 22u) ^ w;
   }
@@ -95,6 +96,20 @@ inline uint32_t pcg_hash(uint32_t in) {  // Sampler.h:32-37
 inline uint32_t path_seed(uint32_t pixel, uint32_t sample, uint64_t seed) {
   uint32_t s32 = (uint32_t)(seed ^ (seed >> 32));
   return pcg_hash(pixel ^ pcg_hash(sample ^ pcg_hash(s32)));
+}
+
+// orc_config.rng_streams (no counterpart in the reference): state and increment of a sample's generator are the
+// two halves of a 64-bit bijective mix (xor with the seed, then MurmurHash3's finaliser) of (sample, pixel).
+inline Rng stream_rng(uint32_t pixel, uint32_t sample, uint64_t seed) {
+  uint64_t k = (((uint64_t)sample << 32) | pixel) ^ seed;
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ull;
+  k ^= k >> 33;
+  Rng g{(uint32_t)k};
+  g.inc = (uint32_t)(k >> 32) | 1u;
+  return g;
 }
 
 // ----------------------------------------------------------------------------
@@ -684,6 +699,7 @@ inline V3 trace_normals(const Scene& S, V3 o, V3 d, bool use_bvh, uint32_t& boun
 inline V3 sample_pixel(const Scene& S, uint32_t px, uint32_t py, uint32_t sample, uint64_t seed,
                        V3 cam_offset, bool use_bvh, uint32_t& bounces, uint64_t& nee) {
   Rng g{path_seed(px + py * S.cfg.width, sample, seed)};
+  if (S.cfg.rng_streams) g = stream_rng(px + py * S.cfg.width, sample, seed);
   float jx = g.uniform();
   float jy = g.uniform();
   float fx = (float)(int)px + jx - 0.5f;

@@ -88,6 +88,8 @@ typedef struct {
   int32_t integrator;   /* 0 pathTrace, 1 rayTraceNormals */
   float focal_length, lens_radius; /* thin lens: 2.4, 0.09 */
   float stretch_x, stretch_y;      /* orthogonal */
+  int32_t rng_streams;  /* 0: the reference's Pcg; 1: an odd increment of its own per sample (the library's opt-in
+                           mode for renders of more than 2^32 samples; not in the reference) */
 } orc_config;
 
 typedef struct {

@@ -52,6 +52,7 @@ class CConfig(C.Structure):
         ("stretch_x", C.c_float), ("stretch_y", C.c_float),
         ("device", C.c_int32), ("pool_paths", C.c_uint32),
         ("finish_paths", C.c_uint32), ("result_buffer_mib", C.c_uint32), ("primary_rays", C.c_int32), ("fused_trace", C.c_int32),
+        ("rng_streams", C.c_int32),
     ]
 
 
@@ -99,7 +100,7 @@ SYMBOLS = [
     "rtx_reset_stats", "rtx_set_profiling", "rtx_accum_alloc", "rtx_accum_free", "rtx_accum_clear",
     "rtx_accum_upload", "rtx_debug_pcg", "rtx_trace_closest_noalloc",
     "rtx_comm_create_id", "rtx_comm_init", "rtx_comm_reduce", "rtx_comm_destroy", "rtx_stream_synchronize",
-    "rtx_render_async", "rtx_wait",
+    "rtx_render_async", "rtx_wait", "rtx_debug_streams",
 ]
 
 COMM_ID_BYTES = 128
@@ -141,6 +142,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.rtx_accum_clear.argtypes = [vp, vp, vp]
     lib.rtx_accum_upload.argtypes = [vp, vp, vp, vp]
     lib.rtx_debug_pcg.argtypes = [vp, u32, u32, vp, vp, vp]
+    lib.rtx_debug_streams.argtypes = [vp, u32, u32, u64, vp, vp]
     lib.rtx_comm_create_id.argtypes = [C.c_char_p]
     lib.rtx_comm_init.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
     lib.rtx_comm_reduce.argtypes = [vp, vp, C.c_int, vp]
@@ -175,6 +177,7 @@ class Config:
     result_buffer_mib: int = 0
     primary_rays: int = 0
     fused_trace: int = 0
+    rng_streams: int = 0
 
     def to_c(self) -> CConfig:
         c = CConfig()
@@ -188,6 +191,7 @@ class Config:
         c.finish_paths, c.result_buffer_mib = self.finish_paths, self.result_buffer_mib
         c.primary_rays = self.primary_rays
         c.fused_trace = self.fused_trace
+        c.rng_streams = self.rng_streams
         return c
 
 
@@ -383,6 +387,10 @@ class Renderer:
         rnd, uni, hsh = np.empty(n, np.uint32), np.empty(n, np.float32), np.empty(n, np.uint32)
         self._check(self.lib.rtx_debug_pcg(self._ctx, seed, n, _ptr(rnd), _ptr(uni), _ptr(hsh)))
         return rnd, uni, hsh
+
+    def debug_streams(self, out_dev, spp: int, sample_base: int = 0, seed: int = 0x5EED, stream: int = 0):
+        """state | increment << 32 of every sample's generator into a device array of width*height*spp uint64."""
+        self._check(self.lib.rtx_debug_streams(self._ctx, spp, sample_base, seed, _dev_ptr(out_dev), stream))
 
     # -- statistics ------------------------------------------------------------------
     def stats(self) -> Stats:

@@ -46,16 +46,36 @@ __device__ __forceinline__ float std_max(float a, float b) { return (a < b) ? b 
 __device__ __forceinline__ float std_min(float a, float b) { return (b < a) ? b : a; }
 __device__ __forceinline__ float vmax3(f3 a) { return std_max(a.x, std_max(a.y, a.z)); }
 
-// Pcg, reference Sampler.h:24-41.
-__device__ __forceinline__ uint32_t pcg_next(uint32_t& s) {
-  uint32_t old = s;
-  s = s * 747796405u + 2891336453u;
+// Pcg, reference Sampler.h:24-41: state and the increment of its step.  The reference's increment is the constant
+// kPcgIncrement for every generator; rtx_config.rng_streams gives every sample an odd increment of its own, which
+// puts it on a cycle of its own (stream_start).
+constexpr uint32_t kPcgIncrement = 2891336453u;
+struct Rng {
+  uint32_t s, inc;
+};
+__device__ __forceinline__ uint32_t pcg_next(Rng& g) {
+  uint32_t old = g.s;
+  g.s = g.s * 747796405u + g.inc;
   uint32_t w = ((old >> ((old >> 28u) + 4u)) ^ old) * 277803737u;
   return (w >> 22u) ^ w;
 }
-__device__ __forceinline__ float pcg_uniform(uint32_t& s) {
-  float u = (float)pcg_next(s) * 0x1p-32f;
+__device__ __forceinline__ float pcg_uniform(Rng& g) {
+  float u = (float)pcg_next(g) * 0x1p-32f;
   return std_min(0x1.fffffep-1f, u);
+}
+// rtx_config.rng_streams: the generator of sample `sample` of pixel `pixel`.  The 64-bit key (sample, pixel) goes
+// through a bijection of the 64-bit integers (xor with the seed, then the finaliser of MurmurHash3: xor-shifts and
+// odd multipliers); the low word is the state, the high word with its lowest bit set the increment.  Two samples
+// get the same (state, increment) only if their images differ in bit 32 alone: with n samples about n^2 / 2^65
+// such pairs are expected, 31 for the 3.4e10 samples of a 3840x2160 frame at 4096 per pixel.
+__host__ __device__ __forceinline__ unsigned long long stream_mix(uint32_t pixel, uint32_t sample, unsigned long long seed) {
+  unsigned long long k = (((unsigned long long)sample << 32) | pixel) ^ seed;
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ull;
+  k ^= k >> 33;
+  return k;
 }
 __host__ __device__ __forceinline__ uint32_t pcg_hash(uint32_t in) {
   uint32_t st = in * 747796405u + 2891336453u;

@@ -84,6 +84,7 @@ struct SceneDev {
   int sky;
   uint32_t max_bounces;
   int integrator;
+  int rng_streams;     // rtx_config.rng_streams: every sample on a generator cycle of its own
   int carries_colour;  // 0: nothing in the scene emits and there are no lights, so a path's colour and
                        // nee_pdf stay exactly 0 until it ends; the queues then skip them (s1)
 };
@@ -104,6 +105,7 @@ struct Queue {
   float4* s1;
   uint2* s2;
   uint32_t* depth;  // bounces so far; touched only when max_bounces != 0
+  uint32_t* inc;    // the generator's increment; touched only with rng_streams
 };
 
 struct ShadowQueue {
@@ -150,6 +152,8 @@ struct RenderParams {
   uint32_t band_pixels;  // (row1-row0)*width
   uint32_t sample_base;  // sample index of ordinal 0
   uint32_t seed32;       // seed folded to 32 bits
+  unsigned long long seed64;  // the seed as given (rng_streams)
+  int rng_streams;
 };
 
 #ifndef RTX_FULL_RECORD_READS
@@ -1098,7 +1102,7 @@ __device__ __forceinline__ f3 rot_vectors_apply(f3 a, f3 b, f3 v) {
 
 // cosineSampleHemisphere, Integrator.h:18-25.  U*2.0f is a float product, the
 // product with M_PI is taken in double and narrowed.
-__device__ __forceinline__ f3 cosine_sample_hemisphere(uint32_t& rng) {
+__device__ __forceinline__ f3 cosine_sample_hemisphere(Rng& rng) {
   float r_sqr = pcg_uniform(rng);
   float phi = (float)((double)(pcg_uniform(rng) * 2.0f) * 3.14159265358979323846);
   float r = sqrtf(r_sqr);
@@ -1176,12 +1180,18 @@ __device__ __forceinline__ uint32_t wave_path_slot(const PathTicket& tk) {
 // camera's draws.  A pure function of k: a kernel can recompute a fresh path's ray
 // instead of reading it back (see Primary).
 __device__ __forceinline__ void primary_ray(const CameraDev& cam, const RenderParams& rp, uint32_t k, f3& o, f3& d,
-                                            uint32_t& rng) {
+                                            Rng& rng, bool streams) {
   const uint32_t in_band = k % rp.band_pixels;
   const uint32_t sample = rp.sample_base + k / rp.band_pixels;
   const uint32_t pixel = rp.row0 * cam.width + in_band;
   const uint32_t px = pixel % cam.width, py = pixel / cam.width;
-  rng = pcg_hash(pixel ^ pcg_hash(sample ^ pcg_hash(rp.seed32)));
+  rng.s = pcg_hash(pixel ^ pcg_hash(sample ^ pcg_hash(rp.seed32)));
+  rng.inc = kPcgIncrement;
+  if (streams) {  // (= rp.rng_streams; from the caller's copy of the scene, which a kernel built for a scene knows)
+    const unsigned long long m = stream_mix(pixel, sample, rp.seed64);
+    rng.s = (uint32_t)m;
+    rng.inc = (uint32_t)(m >> 32) | 1u;
+  }
   float jx = pcg_uniform(rng);
   float jy = pcg_uniform(rng);
   float fx = (float)(int)px + jx - 0.5f;
@@ -1227,7 +1237,8 @@ struct Primary {
 struct PathState {
   f3 o, d, att, col;
   float mis_pdf, nee_pdf;
-  uint32_t ordinal, rng, depth;
+  uint32_t ordinal, depth;
+  Rng rng;
 };
 struct ShadowReq {
   f3 d, contrib;
@@ -1243,7 +1254,7 @@ __device__ __forceinline__ void load_path(const SceneDev& sc, const Queue& q, ui
   float4 s0 = make_float4(1.0f, 1.0f, 1.0f, -1.0f);
   float4 s1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   if (fresh && pr.recompute) {
-    primary_ray(pr.cam, pr.rp, fresh_k, p.o, p.d, p.rng);
+    primary_ray(pr.cam, pr.rp, fresh_k, p.o, p.d, p.rng, sc.rng_streams != 0);
     p.ordinal = fresh_k;
     p.depth = 0;
   } else {
@@ -1257,7 +1268,8 @@ __device__ __forceinline__ void load_path(const SceneDev& sc, const Queue& q, ui
     p.o = mk3(r0.x, r0.y, r0.z);
     p.d = mk3(r0.w, r1.x, r1.y);
     p.ordinal = s2.x;
-    p.rng = s2.y;
+    p.rng.s = s2.y;
+    p.rng.inc = sc.rng_streams ? q.inc[i] : kPcgIncrement;
     p.depth = sc.max_bounces ? q.depth[i] : 0;
   }
   p.att = mk3(s0.x, s0.y, s0.z);
@@ -1270,8 +1282,9 @@ __device__ __forceinline__ void store_path(const SceneDev& sc, const Queue& q, u
   q.r1[i] = make_float2(p.d.y, p.d.z);
   q.s0[i] = make_float4(p.att.x, p.att.y, p.att.z, p.mis_pdf);
   if (sc.carries_colour) q.s1[i] = make_float4(p.col.x, p.col.y, p.col.z, p.nee_pdf);
-  q.s2[i] = make_uint2(p.ordinal, p.rng);
+  q.s2[i] = make_uint2(p.ordinal, p.rng.s);
   if (sc.max_bounces) q.depth[i] = p.depth;
+  if (sc.rng_streams) q.inc[i] = p.rng.inc;
 }
 
 // The body of the loop at reference Integrator.h:108-285 for a path whose closest hit (t, id) is known, in two
@@ -1588,15 +1601,16 @@ __global__ __launch_bounds__(256) void k_generate(Queue q, const SegCounter* seg
   if (j >= seg[s].gen_count) return;
   const uint32_t ordinal = (uint32_t)(seg[s].gen_ordinal0 + j);
   f3 o, d;
-  uint32_t rng;
-  primary_ray(cam, rp, ordinal, o, d, rng);
+  Rng rng;
+  primary_ray(cam, rp, ordinal, o, d, rng, rp.rng_streams != 0);
   // A fresh path: only the ray, the sample ordinal and the generator are stored
   // (see load_path).
   const uint32_t slot = s * rp.cap + seg[s].gen_slot0 + j;
   q.r0[slot] = make_float4(o.x, o.y, o.z, d.x);
   q.r1[slot] = make_float2(d.y, d.z);
-  q.s2[slot] = make_uint2(ordinal, rng);
+  q.s2[slot] = make_uint2(ordinal, rng.s);
   if (use_depth) q.depth[slot] = 0;
+  if (rp.rng_streams) q.inc[slot] = rng.inc;
 }
 
 // Dynamic LDS of the traversal kernels: the per-lane stacks (lds_entries x BLOCK
@@ -1673,8 +1687,8 @@ __global__ __launch_bounds__(BLOCK, MODE == kGlobalBvh2 ? 4 : 8) void k_intersec
     }
     f3 o = mk3(a.x, a.y, a.z), d = mk3(a.w, b.x, b.y);
     if (j >= computed0) {
-      uint32_t rng;
-      primary_ray(prp->cam, prp->rp, k0 + (j - computed0), o, d, rng);
+      Rng rng;
+      primary_ray(prp->cam, prp->rp, k0 + (j - computed0), o, d, rng, sc.rng_streams != 0);
     }
     float t;
     uint32_t id;
@@ -2082,7 +2096,7 @@ __global__ __launch_bounds__(BLOCK, MODE == kLdsLeafTasks ? 7 : 8) void k_trace_
                                                        SegCounter* seg, int qi, uint32_t cap, float* res,
                                                        TraceParams tp, const Primary* __restrict__ prp, Summary* sum) {
   // PLAIN >= 1: the host has seen that the scene has no boxes and no planes and that the call is the path tracer
-  // without a bounce limit (what the reference's scenes are): with these known when the kernel is built, their
+  // without a bounce limit, with the reference's one generator cycle (what the reference's scenes are): with these known when the kernel is built, their
   // branches, and the scalar registers that held their operands, are gone.  PLAIN == 2: under the sky as well, with
   // nothing that emits and a handful of surfaces (the reference's sphere scenes).
   if constexpr (PLAIN >= 1) {
@@ -2090,6 +2104,7 @@ __global__ __launch_bounds__(BLOCK, MODE == kLdsLeafTasks ? 7 : 8) void k_trace_
     sc.num_planes = 0;
     sc.integrator = 0;
     sc.max_bounces = 0;
+    sc.rng_streams = 0;
   }
   if constexpr (PLAIN == 2) {
     sc.sky = 1;
@@ -2393,6 +2408,7 @@ __global__ __launch_bounds__(BLOCK) void k_finish(SceneDev sc, Queue q, const Se
     sc.num_planes = 0;
     sc.integrator = 0;
     sc.max_bounces = 0;
+    sc.rng_streams = 0;
   }
   if constexpr (PLAIN == 2) {
     sc.sky = 1;
@@ -2622,13 +2638,32 @@ __global__ __launch_bounds__(BLOCK) void k_trace_occluded(SceneDev sc, const flo
 // and thread 2 writes pcg_hash(seed + i).
 __global__ void k_debug_pcg(uint32_t seed, uint32_t n, uint32_t* rand_out, float* uniform_out, uint32_t* hash_out) {
   const uint32_t which = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t state = seed;
+  Rng state = {seed, kPcgIncrement};
   if (which == 0 && rand_out)
     for (uint32_t i = 0; i < n; i++) rand_out[i] = pcg_next(state);
   if (which == 1 && uniform_out)
     for (uint32_t i = 0; i < n; i++) uniform_out[i] = pcg_uniform(state);
   if (which == 2 && hash_out)
     for (uint32_t i = 0; i < n; i++) hash_out[i] = pcg_hash(seed + i);
+}
+
+// The generator every sample of a render call starts with, as primary_ray sets it: out[k] = state | increment << 32
+// for the k-th sample of the call (sample rp.sample_base + k / band_pixels of pixel k mod band_pixels of the band).
+__global__ void k_debug_streams(CameraDev cam, RenderParams rp, unsigned long long n, unsigned long long* out) {
+  const unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t in_band = (uint32_t)(k % rp.band_pixels);
+  const uint32_t sample = rp.sample_base + (uint32_t)(k / rp.band_pixels);
+  const uint32_t pixel = rp.row0 * cam.width + in_band;
+  Rng g;
+  g.s = pcg_hash(pixel ^ pcg_hash(sample ^ pcg_hash(rp.seed32)));
+  g.inc = kPcgIncrement;
+  if (rp.rng_streams) {
+    const unsigned long long m = stream_mix(pixel, sample, rp.seed64);
+    g.s = (uint32_t)m;
+    g.inc = (uint32_t)(m >> 32) | 1u;
+  }
+  out[k] = (unsigned long long)g.s | ((unsigned long long)g.inc << 32);
 }
 
 __global__ void k_resolve(const float* accum, float* out, size_t n, float spp) {

@@ -267,7 +267,7 @@ struct rtx_ctx {
   DevBuf<float4> r0[2], s0[2], s1[2], sq0, sq1, sq2;
   DevBuf<float2> r1[2];
   DevBuf<uint2> s2[2], hits;
-  DevBuf<uint32_t> depth[2];
+  DevBuf<uint32_t> depth[2], inc[2];
   DevBuf<rtx::SegCounter> seg;
   DevBuf<rtx::Summary> sum;
   DevBuf<rtx::Primary> primary;  // written by k_begin at the start of every chunk
@@ -323,6 +323,7 @@ Queue queue_of(rtx_ctx* c, int i) {
   q.s1 = c->s1[i].p;
   q.s2 = c->s2[i].p;
   q.depth = c->depth[i].p;
+  q.inc = c->inc[i].p;
   return q;
 }
 
@@ -370,7 +371,7 @@ void free_ctx(rtx_ctx* c) {
   c->light0.release(); c->light1.release(); c->light2.release(); c->light3.release();
   for (int i = 0; i < 2; i++) {
     c->r0[i].release(); c->r1[i].release(); c->s0[i].release(); c->s1[i].release();
-    c->s2[i].release(); c->depth[i].release();
+    c->s2[i].release(); c->depth[i].release(); c->inc[i].release();
   }
   c->sq0.release(); c->sq1.release(); c->sq2.release(); c->hits.release(); c->seg.release(); c->sum.release(); c->primary.release(); c->spill.release();
   c->resolve_tmp.release(); c->res.release();
@@ -402,6 +403,8 @@ static int impl_create(const rtx_config* cfg, rtx_ctx** out) {
     return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_create: bad primary_rays");
   if (cfg->fused_trace < 0 || cfg->fused_trace > 2)
     return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_create: bad fused_trace");
+  if (cfg->rng_streams < 0 || cfg->rng_streams > 1)
+    return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_create: bad rng_streams");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev == 0)
@@ -473,6 +476,7 @@ static int impl_create(const rtx_config* cfg, rtx_ctx** out) {
     CTX_TRY(c->s1[i].alloc(pool));
     CTX_TRY(c->s2[i].alloc(pool));
     if (cfg->max_bounces) CTX_TRY(c->depth[i].alloc(pool));
+    if (cfg->rng_streams) CTX_TRY(c->inc[i].alloc(pool));
   }
   CTX_TRY(c->sq0.alloc(pool));
   CTX_TRY(c->sq1.alloc(pool));
@@ -793,6 +797,7 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
   d.sky = c->cfg.sky;
   d.max_bounces = c->cfg.max_bounces;
   d.integrator = c->cfg.integrator;
+  d.rng_streams = c->cfg.rng_streams;
   bool emits = !l0.empty();
   for (const float4& m : m0) emits = emits || m.w > 0.0f;
   for (const float4& m : sp1) emits = emits || m.w > 0.0f;
@@ -975,7 +980,7 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
   const int few_bounces = c->hooks.few_bounces;
   // (a scene of triangles and spheres, path-traced without a bounce limit: kernels built for exactly that)
   const bool plain = c->scene.num_boxes == 0 && c->scene.num_planes == 0 && c->scene.integrator == 0 &&
-                     c->scene.max_bounces == 0 && !c->hooks.no_plain_kernels;
+                     c->scene.max_bounces == 0 && c->scene.rng_streams == 0 && !c->hooks.no_plain_kernels;
   const bool open_sky = c->scene.sky == 1 && c->scene.carries_colour == 0 && c->scene.few_surfaces == 1;
   const int fused_block = c->lds_scene_bytes <= kFusedSmallSceneBytes ||
                                   (size_t)c->stack_entries * 256 * sizeof(int) + scene_lds > kLdsLaunchMaxBytes
@@ -1320,6 +1325,8 @@ static int render_frame(rtx_ctx* c, float* accum_dev, uint32_t spp, uint32_t sam
   rp.row0 = row0;
   rp.band_pixels = (row1 - row0) * c->cfg.width;
   rp.seed32 = (uint32_t)(seed ^ (seed >> 32));
+  rp.seed64 = seed;
+  rp.rng_streams = c->cfg.rng_streams;
 
   // The result buffer holds 3 floats per sample of a chunk; a call with more
   // samples than fit is rendered as several chunks of whole samples-per-pixel.
@@ -1676,6 +1683,30 @@ static int impl_debug_pcg(rtx_ctx* c, uint32_t seed, uint32_t n, uint32_t* rand_
   return rc;
 }
 
+static int impl_debug_streams(rtx_ctx* c, uint32_t spp, uint32_t sample_base, uint64_t seed, uint64_t* out_dev,
+                              void* stream) {
+  if (!c || !out_dev) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_debug_streams: null argument");
+  DeviceGuard g(c->device);
+  if (!g.ok) return fail(RTX_ERR_HIP, "rtx_debug_streams: hipSetDevice failed");
+  rtx::CameraDev cam{};
+  cam.width = c->cfg.width;
+  cam.height = c->cfg.height;
+  rtx::RenderParams rp{};
+  rp.row0 = 0;
+  rp.band_pixels = c->cfg.width * c->cfg.height;
+  rp.sample_base = sample_base;
+  rp.seed32 = (uint32_t)(seed ^ (seed >> 32));
+  rp.seed64 = seed;
+  rp.rng_streams = c->cfg.rng_streams;
+  const unsigned long long n = (unsigned long long)rp.band_pixels * spp;
+  if (n == 0) return RTX_OK;
+  if ((n + 255) / 256 > 0x7fffffffull) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_debug_streams: too many samples in one call");
+  rtx::k_debug_streams<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+      cam, rp, n, reinterpret_cast<unsigned long long*>(out_dev));
+  HIP_TRY(hipGetLastError());
+  return RTX_OK;
+}
+
 static int impl_get_stats(rtx_ctx* c, rtx_stats* out) {
   if (!c || !out) return fail(RTX_ERR_INVALID_ARGUMENT, "rtx_get_stats: null argument");
   if (int rc = wait_frames(c)) return rc;
@@ -1811,6 +1842,9 @@ int rtx_stream_synchronize(rtx_ctx* c, void* stream) {
 }
 int rtx_debug_pcg(rtx_ctx* c, uint32_t seed, uint32_t n, uint32_t* rand_out, float* uniform_out, uint32_t* hash_out) {
   return guarded("rtx_debug_pcg", [&] { return impl_debug_pcg(c, seed, n, rand_out, uniform_out, hash_out); });
+}
+int rtx_debug_streams(rtx_ctx* c, uint32_t spp, uint32_t sample_base, uint64_t seed, uint64_t* out_dev, void* stream) {
+  return guarded("rtx_debug_streams", [&] { return impl_debug_streams(c, spp, sample_base, seed, out_dev, stream); });
 }
 int rtx_get_stats(rtx_ctx* c, rtx_stats* out) {
   return guarded("rtx_get_stats", [&] { return impl_get_stats(c, out); });
