@@ -315,7 +315,8 @@ def build_roofline(workload, m):
     return roof
 
 
-def run_leg(args, workload, world, rank, local_rank, steps, warmup, profile, torch, dist, sync=None, strong=None):
+def run_leg(args, workload, world, rank, local_rank, steps, warmup, profile, torch, dist, sync=None, strong=None,
+            spp_slice=0):
     """Renders `workload` warmup + steps times; returns the measurements of this rank's view."""
     from raytracer_amd.capi import Config, Renderer
     sync = args.sync if sync is None else sync
@@ -328,7 +329,7 @@ def run_leg(args, workload, world, rank, local_rank, steps, warmup, profile, tor
         wl = workloads()[workload]
     W = args.width or wl["width"]
     H = args.height or wl["height"]
-    spp_full = args.spp or wl["spp"]
+    spp_full = spp_slice or args.spp or wl["spp"]   # spp_slice: a leg that renders part of a configuration's samples
     band, replica, replicas = rank % args.tiles, rank // args.tiles, world // args.tiles
     row0, row1 = band * H // args.tiles, (band + 1) * H // args.tiles
     if strong:
@@ -612,9 +613,17 @@ def main():
     # Further single-GPU legs: BASELINE.json's other configurations that fit one GPU.
     extra = {}
     if world == 1 and default_run:
-        for name, steps, warmup in (("sample3_mis_cornell", 2, 1), ("mesh_1m", 2, 1), ("sample1_diffuse", 20, 3)):
-            extra[name] = run_leg(args, name, 1, 0, local_rank, steps=steps, warmup=warmup,
-                                  profile=not args.no_profile, torch=torch, dist=dist, sync=False, strong=False)
+        # (leg, workload, samples per pixel rendered (0: the workload's own), steps, warm-up steps)
+        for leg, name, spp_slice, steps, warmup in (
+                ("sample3_mis_cornell", "sample3_mis_cornell", 0, 2, 1),            # the scene of the >= 100x target
+                ("mesh_1m", "mesh_1m", 0, 2, 1),                                    # configs[3]
+                ("sample1_diffuse", "sample1_diffuse", 0, 20, 3),                   # configs[0]
+                ("sample3_mis_cornell_1024spp", "sample3_mis_cornell", 1024, 1, 1),  # configs[2] on one GPU
+                ("mis_4k_128_of_4096spp", "mis_4k", 128, 1, 1)):                    # configs[4]: one GPU's share of 32
+            extra[leg] = run_leg(args, name, 1, 0, local_rank, steps=steps, warmup=warmup,
+                                 profile=not args.no_profile, torch=torch, dist=dist, sync=False, strong=False,
+                                 spp_slice=spp_slice)
+            extra[leg]["workload_name"] = name
 
     if rank == 0:
         W, H, spp_full, info = m["W"], m["H"], m["spp_full"], m["info"]
@@ -683,9 +692,10 @@ def main():
         if extra:
             legs = {}
             for name, mm in extra.items():
-                legs[name] = leg_report(name, mm, cpu_budget_s=4.0, no_cpu=args.no_cpu, whole_cpu=name == "sample1_diffuse")
+                legs[name] = leg_report(mm["workload_name"], mm, cpu_budget_s=3.0, no_cpu=args.no_cpu,
+                                        whole_cpu=name == "sample1_diffuse")
             out["legs"] = legs
-            out["mis_cornell"] = legs.get("sample3_mis_cornell")
+            out["mis_cornell"] = "legs.sample3_mis_cornell"
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -54,8 +54,9 @@ int fail_nothrow(int code, const char* what, const char* detail) noexcept {
 
 // k_intersect_wide: waves a launch starts (flat from 28 672 to 250 000 on the 1 M-triangle mesh; with only as
 // many as the chip holds, 7 168, every segment ends at the same moment and the launch takes 25 % longer),
-// and the idle lanes at which a wave stops to supply them: 32 where the tree is larger than one L2 (mesh: 8
-// lanes 31.4 ms, 16: 30.8, 24: 29.8, 32: 29.1, 40: 30.7, 48: 33.8 per 32-spp frame), 16 below (3 000-triangle
+// and the idle lanes at which a wave stops to supply them: 24 where the tree is larger than one L2 (mesh, with
+// the halves of a quad in one leaf record: 24 lanes 26.9 ms, 32: 27.6, 40: 30.3 per 32-spp frame; with one record
+// per triangle it was 8 lanes 31.4, 16: 30.8, 24: 29.8, 32: 29.1, 40: 30.7, 48: 33.8), 16 below (3 000-triangle
 // soup 35.1 / 34.3 / 35.5 / 36.6 for 8 / 16 / 24 / 32; 3 200-triangle terrain 15.97 / 15.91 / 16.4 / 16.8).
 constexpr uint32_t kWideWaves = 40960;
 constexpr size_t kWideLargeTreeBytes = 4u << 20;
@@ -804,7 +805,7 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
   d.carries_colour = emits ? 1 : 0;
   c->stack_entries = stack_entries;
   c->lds_scene_bytes = (nodes.size() / 4 + nt) * rtx::kLdsRecordStride * sizeof(float4);  // as stage_geom_lds lays it out
-  c->wide_refill_lanes = (nodes.size() + (size_t)nt * 4) * sizeof(float4) > kWideLargeTreeBytes ? 32 : 16;
+  c->wide_refill_lanes = (nodes.size() + (size_t)nt * 4) * sizeof(float4) > kWideLargeTreeBytes ? 24 : 16;
   if (hk.wide_refill_lanes >= 0) c->wide_refill_lanes = (uint32_t)std::min(64, std::max(1, hk.wide_refill_lanes));
   if (hk.shadow_refill_lanes >= 0) c->shadow_refill_lanes = (uint32_t)std::min(64, hk.shadow_refill_lanes);
   if (bvh.width == 4)
