@@ -46,7 +46,7 @@ __global__ __launch_bounds__(BLOCK) void k_trace_closest(SceneDev sc, const floa
       prim[i] = k;
     } else {
       kind[i] = 1;
-      prim[i] = __float_as_uint(sc.tris[4 * (size_t)id].w);
+      prim[i] = sc.slot_prim[id];
     }
   }
   t_out[i] = t;

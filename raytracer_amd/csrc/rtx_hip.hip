@@ -257,6 +257,7 @@ struct rtx_ctx {
   bool have_scene = false;
   DevBuf<float4> nodes, tris, tri_nrm, tri_mat, leaf_box, mat0, sph0, sph1, box0, box1, pln0, pln1, light0, light1, light2, light3;
   DevBuf<int> mat1, tri_surf, sph2, sph3;
+  DevBuf<uint32_t> slot_prim;
   rtx::SceneDev scene{};
   rtx_scene_info info{};
   int stack_entries = 8;    // stack entries per lane kept in LDS
@@ -366,7 +367,7 @@ void free_ctx(rtx_ctx* c) {
     if (Rccl* r = rccl()) (void)r->CommDestroy(c->comm);
     c->comm = nullptr;
   }
-  c->nodes.release(); c->tris.release(); c->tri_nrm.release(); c->tri_mat.release(); c->tri_surf.release(); c->leaf_box.release();
+  c->nodes.release(); c->tris.release(); c->tri_nrm.release(); c->slot_prim.release(); c->tri_mat.release(); c->tri_surf.release(); c->leaf_box.release();
   c->mat0.release(); c->mat1.release(); c->sph0.release(); c->sph1.release(); c->sph2.release(); c->sph3.release();
   c->box0.release(); c->box1.release(); c->pln0.release(); c->pln1.release();
   c->light0.release(); c->light1.release(); c->light2.release(); c->light3.release();
@@ -587,33 +588,70 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
     const float len = std::sqrt(nx * nx + ny * ny + nz * nz);
     tn[slot] = make_float4(nx / len, ny / len, nz / len, fmi);
   }
-  // Wide tree: a leaf whose two triangles are the halves of a fan-tessellated quad, (a, b, c) then (a, c, d) bit for
-  // bit, becomes one record of the four vertices (rtx::pair_intersect); its leaf word gets kLeafPairFlag.  The record
-  // of the second slot stays as it is (nothing fetches it during a walk; its primitive id is still looked up there).
-  if (bvh.width == 4 && !hk.no_leaf_pairs) {
+  // Wide tree: the triangle records are re-packed as leaf records, in leaf order and without gaps, and a leaf word
+  // counts in records.  A leaf whose two triangles are the halves of a fan-tessellated quad, (a, b, c) then (a, c, d)
+  // bit for bit, is ONE record of the four vertices (rtx::pair_intersect; kLeafPairFlag in its leaf word); any other
+  // triangle keeps a record of its own.  Row 2 of a record carries the triangle slot of its (first) triangle, which
+  // is what a hit reports (the per-slot arrays tri_nrm and slot_prim are unchanged).  Dense records matter because the
+  // L2 fetches 128-byte lines: two neighbouring leaves then share a line, where a pair record used to share it with the
+  // unused record of its second slot.
+  if (bvh.width == 4) {
+    std::vector<uint8_t> leaf_count(nt, 0);  // by first slot
     for (size_t k = 3; k < nodes.size(); k += 4) {
       int refs[4];
       std::memcpy(refs, &nodes[k], 16);
-      for (int& r : refs) {
-        if (r >= 0 || r == rtx::kTraversalDone) continue;
-        const uint32_t leaf = ~(uint32_t)r;
-        if ((leaf & 7u) != 1u) continue;  // leaves of exactly two
-        const uint32_t first = leaf >> 3;
-        const uint32_t p0 = bvh.order[first], p1 = bvh.order[first + 1];
-        const float* t0 = s->triangles + 9 * (size_t)p0;
+      for (int r : refs)
+        if (r < 0 && r != rtx::kTraversalDone) leaf_count[~(uint32_t)r >> 3] = (uint8_t)((~(uint32_t)r & 7u) + 1u);
+    }
+    std::vector<uint32_t> word_of_slot(nt, 0);  // new leaf word, by first slot
+    std::vector<float4> packed;
+    packed.reserve(tr.size());
+    for (size_t first = 0; first < nt;) {
+      const uint32_t cnt = leaf_count[first];
+      if (cnt == 0) return fail(RTX_ERR_HIP, "rtx_set_scene: internal error, a triangle slot outside every leaf");
+      const uint32_t rec = (uint32_t)(packed.size() / 4);
+      const uint32_t p0 = bvh.order[first];
+      const float* t0 = s->triangles + 9 * (size_t)p0;
+      bool pair = false;
+      if (cnt == 2 && !hk.no_leaf_pairs) {
+        const uint32_t p1 = bvh.order[first + 1];
         const float* t1 = s->triangles + 9 * (size_t)p1;
-        if (std::memcmp(t1, t0, 12) != 0 || std::memcmp(t1 + 3, t0 + 6, 12) != 0) continue;
-        float f0, f1;
-        std::memcpy(&f0, &p0, 4);
-        std::memcpy(&f1, &p1, 4);
-        tr[4 * (size_t)first] = make_float4(t0[0], t0[1], t0[2], f0);
-        tr[4 * (size_t)first + 1] = make_float4(t0[3], t0[4], t0[5], f1);
-        tr[4 * (size_t)first + 2] = make_float4(t0[6], t0[7], t0[8], 0.f);
-        tr[4 * (size_t)first + 3] = make_float4(t1[6], t1[7], t1[8], 0.f);
-        r = (int)~(leaf | rtx::kLeafPairFlag);
+        if (std::memcmp(t1, t0, 12) == 0 && std::memcmp(t1 + 3, t0 + 6, 12) == 0) {
+          float f0, f1, fs;
+          const uint32_t slot = (uint32_t)first;
+          std::memcpy(&f0, &p0, 4);
+          std::memcpy(&f1, &p1, 4);
+          std::memcpy(&fs, &slot, 4);
+          packed.push_back(make_float4(t0[0], t0[1], t0[2], f0));
+          packed.push_back(make_float4(t0[3], t0[4], t0[5], f1));
+          packed.push_back(make_float4(t0[6], t0[7], t0[8], fs));
+          packed.push_back(make_float4(t1[6], t1[7], t1[8], 0.f));
+          word_of_slot[first] = (rec << 3) | 1u | rtx::kLeafPairFlag;
+          pair = true;
+        }
       }
+      if (!pair) {
+        for (uint32_t k = 0; k < cnt; k++) {
+          const uint32_t slot = (uint32_t)first + k;
+          float fs;
+          std::memcpy(&fs, &slot, 4);
+          packed.push_back(tr[4 * (size_t)slot]);
+          packed.push_back(tr[4 * (size_t)slot + 1]);
+          packed.push_back(make_float4(tr[4 * (size_t)slot + 2].x, tr[4 * (size_t)slot + 2].y, tr[4 * (size_t)slot + 2].z, fs));
+          packed.push_back(tr[4 * (size_t)slot + 3]);
+        }
+        word_of_slot[first] = (rec << 3) | (cnt - 1u);
+      }
+      first += cnt;
+    }
+    for (size_t k = 3; k < nodes.size(); k += 4) {
+      int refs[4];
+      std::memcpy(refs, &nodes[k], 16);
+      for (int& r : refs)
+        if (r < 0 && r != rtx::kTraversalDone) r = (int)~word_of_slot[~(uint32_t)r >> 3];
       std::memcpy(&nodes[k], refs, 16);
     }
+    tr.swap(packed);
   }
   std::vector<float4> m0(s->num_materials);
   std::vector<int> m1(s->num_materials);
@@ -701,6 +739,7 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
   HIP_TRY(c->nodes.upload(nodes));
   HIP_TRY(c->tris.upload(tr));
   HIP_TRY(c->tri_nrm.upload(tn));
+  HIP_TRY(c->slot_prim.upload(bvh.order));
   HIP_TRY(c->mat0.upload(m0));
   HIP_TRY(c->mat1.upload(m1));
   // Small scenes (everything but the wide tree): the material copied out per triangle slot, so that the loads of
@@ -776,7 +815,7 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
   HIP_TRY(c->light3.upload(l3));
 
   rtx::SceneDev& d = c->scene;
-  d.nodes = c->nodes.p; d.tris = c->tris.p; d.tri_nrm = c->tri_nrm.p;
+  d.nodes = c->nodes.p; d.tris = c->tris.p; d.tri_nrm = c->tri_nrm.p; d.slot_prim = c->slot_prim.p;
   d.mat0 = c->mat0.p; d.mat1 = c->mat1.p;
   d.tri_mat = tm.empty() ? nullptr : c->tri_mat.p;
   d.tri_surf = tm.empty() ? nullptr : c->tri_surf.p;

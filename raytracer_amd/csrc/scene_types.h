@@ -18,7 +18,10 @@ constexpr int kTraversalDone = (int)0x80000000u;
 struct SceneDev {
   const float4* nodes;   // 4 per BVH node (bvh_build.h)
   const float4* tris;    // per triangle slot, one 64-byte record: (a.xyz, primitive id bits),
-                         // (b-a, material index bits), (c-a, 0), ((b-a)x(c-a), 0)
+                         // (b-a, material index bits), (c-a, flags), ((b-a)x(c-a), 0).  Wide tree: leaf records
+                         // instead, densely in leaf order (a leaf word counts in records): the same record with the
+                         // triangle's slot in row 2's last word, or one record for the two halves of a quad (pair_intersect)
+  const uint32_t* slot_prim;  // per triangle slot: the primitive id (the index the caller gave the triangle)
   const float4* tri_nrm; // per triangle slot: (normalize((b-a)x(c-a)), material index bits): what shading needs of
                          // a hit, computed once on the host with the float operations hit_surface would use
   const float4* mat0;    // per material: (albedo.rgb, emission)

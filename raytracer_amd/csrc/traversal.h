@@ -399,7 +399,10 @@ __device__ __forceinline__ void any_leaves(const Geom& g, const Stack& stk, floa
 // on the wide tree is bound by the record fetches that miss the L2, and half of those are triangles.  The edges and
 // normals the single record stores are computed here instead, with the float operations the host uses for it
 // (b + (-a), the cross product without contraction): a hit has the same bits either way.
-//   row 0 (a.xyz, primitive id of (a, b, c))   row 1 (b.xyz, primitive id of (a, c, d))   row 2 (c.xyz, 0)   row 3 (d.xyz, 0)
+//   row 0 (a.xyz, primitive id of (a, b, c))   row 1 (b.xyz, primitive id of (a, c, d))
+//   row 2 (c.xyz, triangle slot of (a, b, c); the other half has the next slot)   row 3 (d.xyz, 0)
+// The wide tree's leaf records are packed in leaf order (rtx_set_scene): a leaf word's upper bits number records, and
+// every record, pair or single, names its triangle slot in row 2.
 constexpr uint32_t kLeafPairFlag = 4u;  // in the low three bits of a leaf word, beside count - 1 = 1
 struct PairHit {
   float t0, t1;  // Triangle::intersect of each half (Obj.h:110-121); INFINITY: rejected
@@ -479,15 +482,16 @@ __device__ __forceinline__ void closest_step(const Geom& g, const Stack& stk, fl
       if (leaf & kLeafPairFlag) {  // both halves of a quad from one record, in slot order
         const PairHit h = pair_intersect(q0, q1, q2, q3, w.o, w.d);
         const uint32_t p0 = __float_as_uint(q0.w), p1 = __float_as_uint(q1.w);
+        const uint32_t slot = __float_as_uint(q2.w);
         if (eps < h.t0 && h.t0 < INFINITY && (h.t0 < best.t || (h.t0 == best.t && p0 < best.prim))) {
           best.t = h.t0;
           best.prim = p0;
-          best.slot = leaf >> 3;
+          best.slot = slot;
         }
         if (eps < h.t1 && h.t1 < INFINITY && (h.t1 < best.t || (h.t1 == best.t && p1 < best.prim))) {
           best.t = h.t1;
           best.prim = p1;
-          best.slot = (leaf >> 3) + 1u;
+          best.slot = slot + 1u;
         }
         w.cur = w.sp == 0 ? (int)kTraversalDone : stk.pop(w.sp);
       } else {
@@ -497,7 +501,7 @@ __device__ __forceinline__ void closest_step(const Geom& g, const Stack& stk, fl
         if (eps < t && t < INFINITY && (t < best.t || (t == best.t && prim < best.prim))) {
           best.t = t;
           best.prim = prim;
-          best.slot = leaf >> 3;
+          best.slot = __float_as_uint(q2.w);
         }
         w.cur = after_triangle(leaf, stk, w.sp);
       }
