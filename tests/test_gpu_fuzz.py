@@ -88,3 +88,31 @@ def test_random_scenes_without_a_tree_keep_their_bits_across_kernels(rtx_lib):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import few_fuzz
     assert few_fuzz.differences(0, 24) == 0
+
+
+@pytest.mark.parametrize("seed", [3, 17, 42, 77, 131])
+def test_random_quad_meshes_on_the_wide_tree(seed, oracle, rtx_lib):
+    """Fan-tessellated quads of random number, extent and size (tools/quad_fuzz.py runs 150 seeds of this): the wide
+    tree with its leaf pairs and packed leaf records against the oracle's linear scan, closest hits bit for bit
+    (kind, primitive, t, normal) and occlusion, rays that start on surfaces included."""
+    rng = np.random.default_rng(seed)
+    sc = scenes.quad_soup(int(rng.integers(150, 4000)), seed=seed, extent=float(rng.uniform(0.3, 1.5)),
+                          size=float(rng.uniform(0.02, 0.6)))
+    cfg = Config(width=64, height=64, pool_paths=1 << 14)
+    osc = oracle.OracleScene(sc, cfg)
+    rays = np.concatenate([scenes.random_rays(6000, seed=seed + 1000), scenes.random_rays(1500, seed=seed + 2000, unit=False)])
+    k, p, t, n = osc.trace_closest(rays)
+    hit = k != 0
+    o = rays[hit, :3] + rays[hit, 3:] * t[hit, None]
+    d = rng.normal(size=o.shape)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([rays, np.concatenate([o, d], 1).astype(np.float32)])
+    dist = rng.uniform(0.0, 3.0, len(rays)).astype(np.float32)
+    with Renderer(cfg) as r:
+        assert r.set_scene(sc).bvh_width == 4
+        gk, gp, gt, gn = r.trace_closest(rays)
+        gocc = r.trace_occluded(rays, dist)
+    wk, wp, wt, wn = osc.trace_closest(rays, use_bvh=False)
+    assert np.array_equal(gk, wk) and np.array_equal(gp, wp) and np.array_equal(gt.view(np.uint32), wt.view(np.uint32))
+    assert np.array_equal(gn[wk != 0].view(np.uint32), wn[wk != 0].view(np.uint32))
+    assert np.array_equal(gocc, osc.trace_occluded(rays, dist, use_bvh=False))
