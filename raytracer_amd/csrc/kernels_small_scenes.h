@@ -71,6 +71,21 @@ __global__ __launch_bounds__(BLOCK, MODE == kGlobalBvh2 ? 4 : 8) void k_intersec
 // none).  The queue holds sc.leaf_task_cap pairs per thread on average (a ray meets 1.3 leaf boxes); a lane whose
 // pairs do not fit tests its leaves itself.  LDS at `ws`: leaf_task_lds_bytes; the caller has set ws[0] to
 // (0, queue capacity, ...) as uint32 before its last barrier.
+#ifdef RTX_PHASE_STATS
+// Diagnostic build only (make EXTRA=-DRTX_PHASE_STATS): shader cycles the waves of the leaf-task bounce kernel
+// spend between the stamps below, summed over the waves of every 64th block; [15] counts those waves.  tools/phase_stats.py reads them.
+__device__ unsigned long long g_phase_stats[16];
+#define RTX_STAMP(clock, k)                                                                   \
+  do {                                                                                        \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                             \
+    if ((threadIdx.x & 63u) == 0 && (blockIdx.x & 63u) == 0) atomicAdd(&g_phase_stats[k], now_ - (clock)); \
+    (clock) = now_;                                                                           \
+  } while (0)
+#else
+#define RTX_STAMP(clock, k) \
+  do {                      \
+  } while (0)
+#endif
 struct LeafTaskHead {
   uint32_t count, valid_end;    // pairs reserved so far; pairs [0, valid_end) are written
   uint32_t count2, valid_end2;  // the same for a second round of tasks in the same launch (no barrier to reset the first)
@@ -81,22 +96,28 @@ struct LeafTaskHead {
 __host__ __device__ constexpr size_t leaf_task_lds_bytes(uint32_t block, uint32_t cap_per_thread) {
   return sizeof(LeafTaskHead) + 4 * kLeafTaskMaxLeaves + (size_t)block * (32 + 8 + 2 * cap_per_thread + 4);
 }
-// Bit l set: the ray of walk `w` meets the box of leaf l between w.tmin and tmax.  The boxes come through the
-// scalar cache; each is requested one test ahead, so that a test does not begin with a wait for its operands.
-__device__ __forceinline__ uint32_t leaf_boxes_met(const SceneDev& sc, const Walk& w, float tmax) {
-  uint32_t mask = 0;
-  const uint32_t nl = sc.num_leaf_boxes;
-  float4 a = sc.leaf_box[0], b = sc.leaf_box[1];
-#pragma unroll 2
-  for (uint32_t l = 0; l < nl; l++) {
-    const uint32_t nx = l + 1u < nl ? l + 1u : l;
-    const float4 na = sc.leaf_box[2 * nx], nb = sc.leaf_box[2 * nx + 1];
-    float tn;
-    if (slab(a.x, a.y, a.z, a.w, b.x, b.y, w.inv, w.add_lo, w.add_hi, w.tmin, tmax, tn)) mask |= 1u << l;
-    a = na;
-    b = nb;
+// mask = 2 mask + (the ray of walk `w` meets the box (a, b) between w.tmin and tmax).  The comparison's result
+// enters the addition as its carry: one instruction where a select, a shift and an or stand otherwise.
+__device__ __forceinline__ void shift_in_box_met(uint32_t& mask, float4 a, float4 b, const Walk& w, float tmax) {
+  float tn, tf;
+  slab_interval(a.x, a.y, a.z, a.w, b.x, b.y, w.inv, w.add_lo, w.add_hi, w.tmin, tmax, tn, tf);
+  asm("v_cmp_le_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(tn), "v"(tf) : "vcc");
+}
+// Bit l set: the ray of walk `w` meets the box of leaf l between w.tmin and tmax.  `lb`: the box list in LDS
+// (stage_leaf_task_geom_lds); every lane reads the same address.  Four boxes a turn, written out (the compiler
+// does not unroll a loop around the asm statement), so that the reads of a turn are in flight together.
+__device__ __forceinline__ uint32_t leaf_boxes_met(const float4* lb, uint32_t nl, const Walk& w, float tmax) {
+  uint32_t mask = 0, l = 0;
+  for (; l + 4 <= nl; l += 4) {
+    const float4 a0 = lb[2 * l], b0 = lb[2 * l + 1], a1 = lb[2 * l + 2], b1 = lb[2 * l + 3];
+    const float4 a2 = lb[2 * l + 4], b2 = lb[2 * l + 5], a3 = lb[2 * l + 6], b3 = lb[2 * l + 7];
+    shift_in_box_met(mask, a0, b0, w, tmax);
+    shift_in_box_met(mask, a1, b1, w, tmax);
+    shift_in_box_met(mask, a2, b2, w, tmax);
+    shift_in_box_met(mask, a3, b3, w, tmax);
   }
-  return mask;
+  for (; l < nl; l++) shift_in_box_met(mask, lb[2 * l], lb[2 * l + 1], w, tmax);
+  return nl != 0 ? __brev(mask) >> (32u - nl) : 0u;  // (the bits arrived in reverse)
 }
 template <int BLOCK>
 __device__ __forceinline__ void leaf_task_begin(const SceneDev& sc, float4* ws) {
@@ -113,7 +134,7 @@ __device__ __forceinline__ void leaf_task_begin(const SceneDev& sc, float4* ws) 
 template <int BLOCK>
 __device__ __forceinline__ void block_closest_by_leaf_tasks(const SceneDev& sc, const Geom& g, float4* ws, bool active,
                                                             f3 o, f3 d, float t_limit, float& best_t,
-                                                            uint32_t& best_slot) {
+                                                            uint32_t& best_slot, unsigned long long& clk) {
   LeafTaskHead* const head = reinterpret_cast<LeafTaskHead*>(ws);
   uint32_t* const leaf_word = reinterpret_cast<uint32_t*>(ws + 1);
   float4* const ray_o = ws + 1 + kLeafTaskMaxLeaves / 4;
@@ -125,7 +146,9 @@ __device__ __forceinline__ void block_closest_by_leaf_tasks(const SceneDev& sc, 
   if (active) {
     Walk w;
     walk_begin<kLdsBvh2>(sc, o, d, w);
-    uint32_t mask = leaf_boxes_met(sc, w, t_limit);
+    RTX_STAMP(clk, 12);
+    uint32_t mask = leaf_boxes_met(g.nodes, sc.num_leaf_boxes, w, t_limit);
+    RTX_STAMP(clk, 13);
     ray_o[tid] = make_float4(o.x, o.y, o.z, 0.0f);
     ray_d[tid] = make_float4(d.x, d.y, d.z, 0.0f);
     best[tid] = ((unsigned long long)__float_as_uint(t_limit) << 32) | 0xffffffffull;  // any hit at t_limit wins over none
@@ -146,7 +169,9 @@ __device__ __forceinline__ void block_closest_by_leaf_tasks(const SceneDev& sc, 
       }
     }
   }
+  RTX_STAMP(clk, 2);
   __syncthreads();
+  RTX_STAMP(clk, 3);
   const uint32_t ntasks = min(head->count, head->valid_end);
   for (uint32_t k = tid; k < ntasks; k += BLOCK) {
     const uint32_t task = tasks[k], r = task >> 5;
@@ -166,7 +191,9 @@ __device__ __forceinline__ void block_closest_by_leaf_tasks(const SceneDev& sc, 
     if (slot != kMiss)
       atomicMin(&best[tid], ((unsigned long long)__float_as_uint(t) << 32) | ((unsigned long long)prim << 16) | slot);
   }
+  RTX_STAMP(clk, 4);
   __syncthreads();
+  RTX_STAMP(clk, 5);
   best_t = t_limit;
   best_slot = kMiss;
   if (active) {
@@ -181,7 +208,7 @@ __device__ __forceinline__ void block_closest_by_leaf_tasks(const SceneDev& sc, 
 // costs little where most segments are free.  The caller has run leaf_task_begin and a barrier since the last call.
 template <int BLOCK, bool SECOND = false>
 __device__ __forceinline__ bool block_any_by_leaf_tasks(const SceneDev& sc, const Geom& g, float4* ws, bool active,
-                                                        f3 o, f3 d, float tfar) {
+                                                        f3 o, f3 d, float tfar, unsigned long long& clk) {
   LeafTaskHead* const head = reinterpret_cast<LeafTaskHead*>(ws);
   uint32_t* const leaf_word = reinterpret_cast<uint32_t*>(ws + 1);
   float4* const ray_o = ws + 1 + kLeafTaskMaxLeaves / 4;
@@ -195,7 +222,7 @@ __device__ __forceinline__ bool block_any_by_leaf_tasks(const SceneDev& sc, cons
   if (active) {
     Walk w;
     walk_begin<kLdsBvh2>(sc, o, d, w);
-    uint32_t mask = leaf_boxes_met(sc, w, tfar);
+    uint32_t mask = leaf_boxes_met(g.nodes, sc.num_leaf_boxes, w, tfar);
     ray_o[tid] = make_float4(o.x, o.y, o.z, tfar);
     ray_d[tid] = make_float4(d.x, d.y, d.z, 0.0f);
     flag[tid] = 0;
@@ -214,7 +241,9 @@ __device__ __forceinline__ bool block_any_by_leaf_tasks(const SceneDev& sc, cons
       }
     }
   }
+  RTX_STAMP(clk, 7);
   __syncthreads();
+  RTX_STAMP(clk, 8);
   const uint32_t ntasks = min(*count, *valid_end);
   for (uint32_t k = tid; k < ntasks; k += BLOCK) {
     const uint32_t task = tasks[k], r = task >> 5;
@@ -227,7 +256,9 @@ __device__ __forceinline__ bool block_any_by_leaf_tasks(const SceneDev& sc, cons
     own &= own - 1u;
     hit = leaf_any<kLdsBvh2>(g, leaf_word[l], o, d, sc.eps, tfar);
   }
+  RTX_STAMP(clk, 9);
   __syncthreads();
+  RTX_STAMP(clk, 10);
   return active && (hit || flag[tid] != 0);
 }
 
@@ -237,7 +268,8 @@ __device__ __forceinline__ bool block_any_by_leaf_tasks(const SceneDev& sc, cons
 // bounce and the hit stays in registers.
 // (eight waves per SIMD: the compiler then keeps to 96 scalar registers as well, which it passed by five
 // otherwise, and a wave of this kernel mostly waits: sample2 8.8 -> 8.3 ms, Cornell's bounces 51.7 -> 49.4)
-// (kLdsLeafTasks: its LDS workspace leaves room for seven blocks of 256 per CU, so seven waves per SIMD it is)
+// (kLdsLeafTasks: 66 vector registers, so seven waves per SIMD; built for eight it spills 51 and Cornell's frame
+// goes from 47 to 55 ms)
 // BOUNCES = 2 (light-free scenes without a tree): a path that goes on after the launch's first bounce makes its
 // second in the same lane.  Such a kernel moves bytes more than it computes (a path is 48 B read and 48 B written per
 // bounce, and four in ten go on), and every second write and read back of a path falls away; the lanes of the
@@ -266,6 +298,12 @@ __global__ __launch_bounds__(BLOCK, MODE == kLdsLeafTasks ? 7 : 8) void k_trace_
   const uint32_t s = blockIdx.y;
   const uint32_t n = seg_paths(seg[s].c[qi]);
   if (blockIdx.x * BLOCK >= n) return;  // whole blocks beyond the fill leave; the rest stay for the barrier and the ballots
+  [[maybe_unused]] unsigned long long clk = 0;
+#ifdef RTX_PHASE_STATS
+  clk = __builtin_amdgcn_s_memtime();
+  if constexpr (MODE == kLdsLeafTasks)
+    if ((threadIdx.x & 63u) == 0 && (blockIdx.x & 63u) == 0) atomicAdd(&g_phase_stats[15], 1ull);
+#endif
   constexpr int WALK = MODE == kLdsLeafTasks ? kLdsBvh2 : MODE;   // (how a lane of this kernel would walk the tree)
   extern __shared__ float4 lds_dyn[];
   Stack stk;
@@ -278,13 +316,16 @@ __global__ __launch_bounds__(BLOCK, MODE == kLdsLeafTasks ? 7 : 8) void k_trace_
   // LDS: [per-lane stacks | scene] for the walks, [scene | leaf-task workspace] for kLdsLeafTasks
   const uint32_t scene_at = MODE == kLdsLeafTasks ? 0u : (tp.lds_entries * BLOCK) / 4;
   float4* const task_ws = lds_dyn + kLdsRecordStride * (sc.num_nodes + sc.num_tris);
-  if constexpr (MODE == kLdsLeafTasks) leaf_task_begin<BLOCK>(sc, task_ws);  // (ahead of the staging's barrier)
-  const Geom geom = WALK == kLdsBvh2 ? stage_geom_lds(sc, lds_dyn + scene_at, threadIdx.x, BLOCK) : global_geom(sc);
   const uint32_t j = blockIdx.x * BLOCK + threadIdx.x;
   const bool active = j < n;
   const uint32_t i = s * cap + j;
-
   PathState p;
+  if constexpr (MODE == kLdsLeafTasks) leaf_task_begin<BLOCK>(sc, task_ws);  // (ahead of the staging's barrier)
+  const Geom geom = MODE == kLdsLeafTasks ? stage_leaf_task_geom_lds(sc, lds_dyn, threadIdx.x, BLOCK)
+                    : WALK == kLdsBvh2   ? stage_geom_lds(sc, lds_dyn + scene_at, threadIdx.x, BLOCK)
+                                         : global_geom(sc);
+  if constexpr (MODE == kLdsLeafTasks) RTX_STAMP(clk, 0);
+
   ShadowReq sr;
   SurfaceHit sh;
   bool alive = false, want_shadow = false, did_nee = false, bad = false;
@@ -292,16 +333,17 @@ __global__ __launch_bounds__(BLOCK, MODE == kLdsLeafTasks ? 7 : 8) void k_trace_
   uint32_t id = kMiss;
   if constexpr (MODE == kLdsLeafTasks) {
     // cast_ray with the mesh part done by the whole block
-    // (requesting the path ahead of the staging, as k_shadow_leaf_tasks does with its samples, measured slower here)
-    p.o = p.d = mk3(0.0f, 0.0f, 0.0f);
     float ts = INFINITY;
     uint32_t sid = kMiss;
+    // (requesting the path ahead of the staging, as k_shadow_leaf_tasks does with its samples: no faster here)
+    p.o = p.d = mk3(0.0f, 0.0f, 0.0f);
     if (active) {
       load_path(sc, in, i, j >= seg[s].gen_slot0, *prp, (uint32_t)seg[s].gen_ordinal0 + (j - seg[s].gen_slot0), p);
       analytic_closest(sc, p.o, p.d, ts, sid);
     }
+    RTX_STAMP(clk, 1);
     uint32_t slot;
-    block_closest_by_leaf_tasks<BLOCK>(sc, geom, task_ws, active, p.o, p.d, ts, t, slot);
+    block_closest_by_leaf_tasks<BLOCK>(sc, geom, task_ws, active, p.o, p.d, ts, t, slot, clk);
     id = slot != kMiss ? slot : sid;
   }
   // Without lights a bounce queues no light sample, so the append counts paths only, and which paths go on is
@@ -342,6 +384,7 @@ __global__ __launch_bounds__(BLOCK, MODE == kLdsLeafTasks ? 7 : 8) void k_trace_
     }
   }
   wave_count(bad, &sum->stat_nan);
+  if constexpr (MODE == kLdsLeafTasks) RTX_STAMP(clk, 6);
   bool queue_sample = want_shadow;
   if constexpr (INLINE_LIGHT_SAMPLES) {
     // The light sample is traced here, as a second round of tasks of the block: it is counted, not queued.
@@ -351,7 +394,7 @@ __global__ __launch_bounds__(BLOCK, MODE == kLdsLeafTasks ? 7 : 8) void k_trace_
       sr.tfar = 0.0f;
     }
     const bool try_light = want_shadow && !analytic_any(sc, p.o, sr.d, sr.tfar);
-    const bool occ = block_any_by_leaf_tasks<BLOCK, true>(sc, geom, task_ws, try_light, p.o, sr.d, sr.tfar);
+    const bool occ = block_any_by_leaf_tasks<BLOCK, true>(sc, geom, task_ws, try_light, p.o, sr.d, sr.tfar, clk);
     if (try_light && !occ) p.col = vadd(p.col, sr.contrib);
     queue_sample = false;
   }
@@ -370,6 +413,7 @@ __global__ __launch_bounds__(BLOCK, MODE == kLdsLeafTasks ? 7 : 8) void k_trace_
     sq.q1[k] = make_float4(sr.d.x, sr.d.y, sr.d.z, __uint_as_float(s * cap + pos));
     sq.q2[k] = make_float4(sr.contrib.x, sr.contrib.y, sr.contrib.z, 0.0f);
   }
+  if constexpr (MODE == kLdsLeafTasks) RTX_STAMP(clk, 11);
 }
 
 // Traces the NEE segments queued by k_shade; an unoccluded one adds its
@@ -411,10 +455,11 @@ __global__ __launch_bounds__(BLOCK, 7) void k_shadow_leaf_tasks(SceneDev sc, Que
     b = sq.q1[k];
   }
   leaf_task_begin<BLOCK>(sc, task_ws);
-  const Geom geom = stage_geom_lds(sc, lds_dyn, threadIdx.x, BLOCK);  // (ends with a barrier)
+  const Geom geom = stage_leaf_task_geom_lds(sc, lds_dyn, threadIdx.x, BLOCK);  // (ends with a barrier)
   const bool free_so_far = active && !analytic_any(sc, mk3(a.x, a.y, a.z), mk3(b.x, b.y, b.z), a.w);
+  [[maybe_unused]] unsigned long long clk = 0;
   const bool occ = block_any_by_leaf_tasks<BLOCK>(sc, geom, task_ws, free_so_far, mk3(a.x, a.y, a.z),
-                                                  mk3(b.x, b.y, b.z), a.w);
+                                                  mk3(b.x, b.y, b.z), a.w, clk);
   if (free_so_far && !occ) add_contribution(paths, sq, k, __float_as_uint(b.w));
 }
 

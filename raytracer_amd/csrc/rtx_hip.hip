@@ -798,7 +798,8 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
       }
     }
     const bool dense = leaf_area >= kLeafTaskMinLeafArea * root_area || hk.leaf_tasks_always;
-    if (lb.size() > 2 * rtx::kLeafTaskMaxLeaves || !dense) lb.clear();
+    // (the list takes the node records' place in the kernels' LDS: stage_leaf_task_geom_lds)
+    if (lb.size() > 2 * rtx::kLeafTaskMaxLeaves || lb.size() > rtx::kLdsRecordStride * (nodes.size() / 4) || !dense) lb.clear();
   }
   HIP_TRY(c->leaf_box.upload(lb));
   HIP_TRY(c->sph0.upload(sp0));
@@ -1806,6 +1807,15 @@ static int impl_accum_upload(rtx_ctx* c, float* p, const float* sums_host, void*
 
 }  // extern "C"
 
+#ifdef RTX_PHASE_STATS
+// Diagnostic build only: reads and clears the phase clocks of the leaf-task bounce kernel (g_phase_stats).
+extern "C" int rtx_debug_phase_stats(unsigned long long out[16]) {
+  static const unsigned long long zero[16] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rtx::g_phase_stats), sizeof(zero)) != hipSuccess) return RTX_ERR_HIP;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(rtx::g_phase_stats), zero, sizeof(zero)) != hipSuccess) return RTX_ERR_HIP;
+  return RTX_OK;
+}
+#endif
 #ifdef RTX_WALK_STATS
 // Diagnostic build only: reads and clears the counters of k_intersect_wide's waves (kernels.h, g_walk_stats).
 extern "C" int rtx_debug_walk_stats(unsigned long long out[8]) {

@@ -202,5 +202,23 @@ __device__ __forceinline__ Geom stage_geom_lds(const SceneDev& sc, float4* dst, 
   g.stride = kLdsRecordStride;
   return g;
 }
+// The same for the kernels that test every leaf's box and never walk (kLdsLeafTasks): the list of leaf boxes, two
+// float4 each, takes the place of the node records (2 n float4 against the 5 (n - 1) of a tree of n leaves; the
+// host checks that it fits), so the triangle records start where they start in the other layout.  The lanes then
+// read a box with two LDS reads of one address (a broadcast), which a wave can have several of in flight; read
+// through the scalar cache, one box at a time for want of scalar registers, the box loop ran at a third of the
+// rate its arithmetic allows.  Geom::nodes is the box list.
+__device__ __forceinline__ Geom stage_leaf_task_geom_lds(const SceneDev& sc, float4* dst, int tid, int nthreads) {
+  const uint32_t nb = 2 * sc.num_leaf_boxes, nt = 4 * sc.num_tris;
+  float4* const tdst = dst + kLdsRecordStride * sc.num_nodes;
+  for (uint32_t k = tid; k < nb; k += nthreads) dst[k] = sc.leaf_box[k];
+  for (uint32_t k = tid; k < nt; k += nthreads) tdst[(k >> 2) * kLdsRecordStride + (k & 3u)] = sc.tris[k];
+  __syncthreads();
+  Geom g;
+  g.nodes = dst;
+  g.tris = tdst;
+  g.stride = kLdsRecordStride;
+  return g;
+}
 
 }  // namespace rtx

@@ -125,15 +125,21 @@ __device__ __forceinline__ float plane_intersect(f3 pt, f3 n, f3 o, f3 d) {
 // by four times that, towards "box larger", so the test stays conservative for any
 // origin.  The comparison's slack covers the relative errors (fma rounding and the
 // reciprocal's ulp).  The inverse is finite (clamped), so no term is NaN.
-__device__ __forceinline__ bool slab(float lox, float hix, float loy, float hiy, float loz, float hiz,
-                                     f3 inv, f3 add_lo, f3 add_hi, float tmin, float tmax, float& tnear) {
+__device__ __forceinline__ void slab_interval(float lox, float hix, float loy, float hiy, float loz, float hiz,
+                                              f3 inv, f3 add_lo, f3 add_hi, float tmin, float tmax, float& tnear,
+                                              float& tfar_slack) {
   float ax = __builtin_fmaf(lox, inv.x, add_lo.x), bx = __builtin_fmaf(hix, inv.x, add_hi.x);
   float ay = __builtin_fmaf(loy, inv.y, add_lo.y), by = __builtin_fmaf(hiy, inv.y, add_hi.y);
   float az = __builtin_fmaf(loz, inv.z, add_lo.z), bz = __builtin_fmaf(hiz, inv.z, add_hi.z);
-  float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
-  float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
-  tnear = tn;
-  return tn <= tf * 1.000001f;
+  tnear = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+  tfar_slack = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax)) * 1.000001f;
+}
+// The box is met where tnear <= tfar_slack.
+__device__ __forceinline__ bool slab(float lox, float hix, float loy, float hiy, float loz, float hiz,
+                                     f3 inv, f3 add_lo, f3 add_hi, float tmin, float tmax, float& tnear) {
+  float tf;
+  slab_interval(lox, hix, loy, hiy, loz, hiz, inv, add_lo, add_hi, tmin, tmax, tnear, tf);
+  return tnear <= tf;
 }
 
 // One triangle of a leaf against the running closest hit, with the rules of
