@@ -72,7 +72,7 @@ __global__ __launch_bounds__(BLOCK, MODE == kGlobalBvh2 ? 4 : 8) void k_intersec
 // pairs do not fit tests its leaves itself.  LDS at `ws`: leaf_task_lds_bytes; the caller has set ws[0] to
 // (0, queue capacity, ...) as uint32 before its last barrier.
 #ifdef RTX_PHASE_STATS
-// Diagnostic build only (make EXTRA=-DRTX_PHASE_STATS): shader cycles the waves of the leaf-task bounce kernel
+// Diagnostic build only (make EXTRA=-DRTX_PHASE_STATS): shader cycles the waves of the bounce kernel k_trace_shade
 // spend between the stamps below, summed over the waves of every 64th block; [15] counts those waves.  tools/phase_stats.py reads them.
 __device__ unsigned long long g_phase_stats[16];
 #define RTX_STAMP(clock, k)                                                                   \
@@ -352,8 +352,13 @@ __global__ __launch_bounds__(BLOCK, MODE == kLdsLeafTasks ? 7 : 8) void k_trace_
   constexpr bool reserve_early = !LIGHTS;  // (LIGHTS: the scene has any, sc.num_lights != 0)
   bool live = active;  // this lane carries a path
   if constexpr (MODE != kLdsLeafTasks) {
+#ifdef RTX_PHASE_STATS
+    if ((threadIdx.x & 63u) == 0 && (blockIdx.x & 63u) == 0) atomicAdd(&g_phase_stats[15], 1ull);
+#endif
+    RTX_STAMP(clk, 0);
     if (active)
       load_path(sc, in, i, j >= seg[s].gen_slot0, *prp, (uint32_t)seg[s].gen_ordinal0 + (j - seg[s].gen_slot0), p);
+    RTX_STAMP(clk, 1);
     if constexpr (BOUNCES > 1) {
       // The first BOUNCES - 1 bounces of a launch: a path that goes on stays in its lane (its state is neither
       // written nor read back), the lanes of the paths that ended idle.  Counted in seg[s].more_bounces.
@@ -363,19 +368,25 @@ __global__ __launch_bounds__(BLOCK, MODE == kLdsLeafTasks ? 7 : 8) void k_trace_
         bool goes_on = false;
         if (live) {
           cast_ray<WALK>(sc, geom, p.o, p.d, stk, t, id);
+          RTX_STAMP(clk, 2);
           goes_on = shade_bounce(sc, global_geom(sc), p, t, id, want_shadow, did_nee, sr);
           if (!goes_on) {
             store_result(res, p.ordinal, p.col);
             bad = bad || colour_not_finite(p.col);
           }
+          RTX_STAMP(clk, 3);
         }
         live = goes_on;
         wave_count(live, &seg[s].more_bounces);
+        RTX_STAMP(clk, 4);
       }
     }
   }
   if (live) {
-    if constexpr (MODE != kLdsLeafTasks) cast_ray<WALK>(sc, geom, p.o, p.d, stk, t, id);
+    if constexpr (MODE != kLdsLeafTasks) {
+      cast_ray<WALK>(sc, geom, p.o, p.d, stk, t, id);
+      RTX_STAMP(clk, 5);
+    }
     alive = reserve_early ? shade_arrive<true>(sc, global_geom(sc), p, t, id, sh)
                           : shade_bounce(sc, global_geom(sc), p, t, id, want_shadow, did_nee, sr);
     if (!alive) {
@@ -384,7 +395,7 @@ __global__ __launch_bounds__(BLOCK, MODE == kLdsLeafTasks ? 7 : 8) void k_trace_
     }
   }
   wave_count(bad, &sum->stat_nan);
-  if constexpr (MODE == kLdsLeafTasks) RTX_STAMP(clk, 6);
+  RTX_STAMP(clk, 6);
   bool queue_sample = want_shadow;
   if constexpr (INLINE_LIGHT_SAMPLES) {
     // The light sample is traced here, as a second round of tasks of the block: it is counted, not queued.
@@ -403,6 +414,7 @@ __global__ __launch_bounds__(BLOCK, MODE == kLdsLeafTasks ? 7 : 8) void k_trace_
     const PathTicket tk = wave_reserve_paths(alive, &seg[s].c[qi ^ 1]);
     if (alive) shade_leave(sc, p, sh, want_shadow, did_nee, sr);
     pos = wave_path_slot(tk);
+    RTX_STAMP(clk, 7);
   } else {
     wave_append(alive, want_shadow, did_nee, &seg[s].c[qi ^ 1], pos, spos);
   }
@@ -413,7 +425,7 @@ __global__ __launch_bounds__(BLOCK, MODE == kLdsLeafTasks ? 7 : 8) void k_trace_
     sq.q1[k] = make_float4(sr.d.x, sr.d.y, sr.d.z, __uint_as_float(s * cap + pos));
     sq.q2[k] = make_float4(sr.contrib.x, sr.contrib.y, sr.contrib.z, 0.0f);
   }
-  if constexpr (MODE == kLdsLeafTasks) RTX_STAMP(clk, 11);
+  RTX_STAMP(clk, 11);
 }
 
 // Traces the NEE segments queued by k_shade; an unoccluded one adds its

@@ -255,6 +255,7 @@ struct rtx_ctx {
 
   // scene
   bool have_scene = false;
+  bool specular_surfaces = false;  // any surface that is not diffuse: paths make long chains of bounces
   DevBuf<float4> nodes, tris, tri_nrm, tri_mat, leaf_box, mat0, sph0, sph1, box0, box1, pln0, pln1, light0, light1, light2, light3;
   DevBuf<int> mat1, tri_surf, sph2, sph3;
   DevBuf<uint32_t> slot_prim;
@@ -660,6 +661,8 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
     m0[i] = make_float4(m.albedo[0], m.albedo[1], m.albedo[2], m.emission);
     m1[i] = m.surface;
   }
+  c->specular_surfaces = false;
+  for (size_t i = 0; i < s->num_materials; i++) c->specular_surfaces |= s->materials[i].surface != RTX_DIFFUSE;
   // Analytic objects: one material list in the order spheres, boxes, planes.
   const size_t nobj = s->num_spheres + s->num_boxes + s->num_planes;
   std::vector<float4> sp0(s->num_spheres), sp1(nobj), bx0(s->num_boxes), bx1(s->num_boxes), pl0(s->num_planes),
@@ -668,6 +671,7 @@ static int impl_set_scene(rtx_ctx* c, const rtx_scene* s) {
   auto put_material = [&](size_t i, const rtx_material& m) {
     sp1[i] = make_float4(m.albedo[0], m.albedo[1], m.albedo[2], m.emission);
     sp2[i] = m.surface;
+    c->specular_surfaces |= m.surface != RTX_DIFFUSE;
   };
   for (size_t i = 0; i < s->num_spheres; i++) {
     const rtx_sphere& q = s->spheres[i];
@@ -1149,17 +1153,30 @@ int render_chunk(rtx_ctx* c, float* accum_band, const rtx::CameraDev& cam, rtx::
       rtx::k_trace_shade<B, M, false><<<dim3(div_up(seg_max_upper, B), nseg), B, LDS, st>>>(                      \
           c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp, sum);                                           \
   } while (0)
-      if (few && c->scene.num_lights == 0 && few_bounces == 2 && plain && open_sky)  // two bounces per launch
-        rtx::k_trace_shade<128, rtx::kFewTriangles, false, false, 2, 2><<<dim3(div_up(seg_max_upper, 128), nseg), 128, 0, st>>>(
-            c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp, sum);
-      else if (few && c->scene.num_lights == 0 && few_bounces == 2 && plain)
-        rtx::k_trace_shade<128, rtx::kFewTriangles, false, false, 2, 1><<<dim3(div_up(seg_max_upper, 128), nseg), 128, 0, st>>>(
-            c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp, sum);
-      else if (few && c->scene.num_lights == 0 && few_bounces == 2)
-        rtx::k_trace_shade<128, rtx::kFewTriangles, false, false, 2><<<dim3(div_up(seg_max_upper, 128), nseg), 128, 0, st>>>(
-            c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp, sum);
+      // Scenes without a tree: no barrier and no LDS, so a block is one wave where waves live long (chains of
+      // specular bounces), and two where they are short enough for the dispatch of blocks to be what limits the
+      // launch.  sample2's frame (glass): 5.54 ms at 128 threads, 5.46 at 64, 5.9 at 256, 6.8 at 512 (waves of a
+      // block leave their slots together); sample1's (diffuse only): 0.42 at 128, 0.44 at 64.
+#define RTX_FEW_LAUNCH(B)                                                                                         \
+  do {                                                                                                            \
+    const dim3 grid(div_up(seg_max_upper, B), nseg);                                                              \
+    if (c->scene.num_lights == 0 && few_bounces == 2 && plain && open_sky) /* two bounces per launch */           \
+      rtx::k_trace_shade<B, rtx::kFewTriangles, false, false, 2, 2><<<grid, B, 0, st>>>(                          \
+          c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp, sum);                                           \
+    else if (c->scene.num_lights == 0 && few_bounces == 2 && plain)                                               \
+      rtx::k_trace_shade<B, rtx::kFewTriangles, false, false, 2, 1><<<grid, B, 0, st>>>(                          \
+          c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp, sum);                                           \
+    else if (c->scene.num_lights == 0 && few_bounces == 2)                                                        \
+      rtx::k_trace_shade<B, rtx::kFewTriangles, false, false, 2><<<grid, B, 0, st>>>(                             \
+          c->scene, qc, qn, sq, seg, cur, cap, c->res.p, tp, prp, sum);                                           \
+    else                                                                                                          \
+      RTX_TRACE_SHADE(B, rtx::kFewTriangles, 0);                                                                  \
+  } while (0)
+      if (few && c->specular_surfaces)
+        RTX_FEW_LAUNCH(64);
       else if (few)
-        RTX_TRACE_SHADE(128, rtx::kFewTriangles, 0);
+        RTX_FEW_LAUNCH(128);
+#undef RTX_FEW_LAUNCH
       else if (inline_light_samples && plain)  // ... and the light sample as a second round of tasks
         rtx::k_trace_shade<256, rtx::kLdsLeafTasks, true, true, 1, 1>
             <<<dim3(div_up(seg_max_upper, 256), nseg), 256,
@@ -1453,6 +1470,7 @@ static void mirror_scene(rtx_ctx* c) {
   t->info = c->info;
   t->stack_entries = c->stack_entries;
   t->trace_mode = c->trace_mode;
+  t->specular_surfaces = c->specular_surfaces;
   t->lds_scene_bytes = c->lds_scene_bytes;
   t->wide_refill_lanes = c->wide_refill_lanes;
   t->shadow_refill_lanes = c->shadow_refill_lanes;

@@ -1,4 +1,4 @@
-"""Where the waves of the leaf-task bounce kernel spend their cycles, from a diagnostic build of the library
+"""Where the waves of the bounce kernel (k_trace_shade) spend their cycles, from a diagnostic build of the library
 (make -C raytracer_amd/csrc OUT=../librtx_hip_ps.so EXTRA=-DRTX_PHASE_STATS).
 usage: RTX_LIB=raytracer_amd/librtx_hip_ps.so python tools/phase_stats.py [WORKLOAD] [spp]"""
 import ctypes as C
@@ -14,6 +14,9 @@ from raytracer_amd.capi import Config, Renderer
 PHASES = ["stage scene in LDS (to barrier)", "load path, analytic objects", "closest: push tasks", "barrier 1",
           "triangle tasks (closest)", "barrier 2", "shade", "analytic any, leaf boxes, push (light sample)",
           "barrier 3", "triangle tasks (any)", "barrier 4", "append, store", "  closest: walk_begin", "  closest: leaf boxes"]
+OTHER = ["start to path request", "load path / primary ray", "first bounce: search", "first bounce: shade, store result",
+         "first bounce: count", "last bounce: search", "last bounce: shade_arrive", "reserve slot, sample next direction",
+         "", "", "", "store path", "", ""]
 name = sys.argv[1] if len(sys.argv) > 1 else "sample3_mis_cornell"
 wl = bench.workloads()[name]
 spp = int(sys.argv[2]) if len(sys.argv) > 2 else 16
@@ -34,5 +37,7 @@ v = list(out)
 waves = v[15]
 total = sum(v[:14])
 print(f"{name}: frame {ms:.1f} ms; {waves} waves sampled, {total / waves:.0f} cycles per wave")
-for k, label in enumerate(PHASES):
-    print(f"  {v[k] / waves:8.0f}  {100 * v[k] / total:5.1f} %  {label}")
+labels = PHASES if v[13] else OTHER   # (only the leaf-task kernel stamps slot 13)
+for k, label in enumerate(labels):
+    if label:
+        print(f"  {v[k] / waves:8.0f}  {100 * v[k] / total:5.1f} %  {label}")
