@@ -48,7 +48,7 @@
 //   kernels_debug.h          k_trace_closest, k_trace_occluded, k_debug_pcg, k_debug_streams
 //
 // Which kernels a frame runs (rtx_hip.hip, render_chunk):
-//   mesh of up to 8 triangles, no lights (sample1, sample2)   k_plan, k_trace_shade<128, kFewTriangles, .., BOUNCES = 2>
+//   mesh of up to 8 triangles, no lights (sample1, sample2)   k_plan, k_trace_shade<64 or 128, kFewTriangles, .., BOUNCES = 2>
 //   tree in LDS, a room of a few surfaces (MIS Cornell)        k_plan, k_trace_shade<256, kLdsLeafTasks, true, true>
 //   tree in LDS otherwise (up to about 200 triangles)          k_plan, k_trace_shade<.., kLdsBvh2>, k_shadow where lit
 //   large mesh (four-child tree in global memory)              k_plan, k_generate, k_intersect_wide,

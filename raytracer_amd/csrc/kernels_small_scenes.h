@@ -62,7 +62,7 @@ __global__ __launch_bounds__(BLOCK, MODE == kGlobalBvh2 ? 4 : 8) void k_intersec
 // Closest mesh hit for the rays of a whole block when the tree has a handful of leaves (Cornell's seventeen).
 // In a walk a ray needs about eight node and 1.2 leaf visits, but its wave runs twenty node rounds and seven
 // leaf rounds, the latter with a sixth of the lanes at work, because the lanes' walks differ.  Here every lane
-// tests the boxes of all leaves (scalar operands, no stack, no divergence; what an ordered walk would have
+// tests the boxes of all leaves (read from LDS as broadcasts, no stack, no divergence; what an ordered walk would have
 // culled behind a hit is a twentieth of the leaf visits in such a scene), the (ray, leaf) pairs go to a queue
 // in LDS, and the block's waves test them in dense batches of 64; a hit is merged into its ray's record with a
 // 64-bit minimum of (t, primitive id, slot): the smallest t and, among equal t, the lowest primitive id, which is
