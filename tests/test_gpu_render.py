@@ -208,7 +208,11 @@ def test_triangle_tests_as_tasks_of_the_block_keep_the_bits(cap, rtx_lib, monkey
              (scenes.soup(57, 0, seed=9, size=0.9), 1), (scenes.soup(9, 2, seed=4, size=0.9), 1),
              # lit meshes of up to eight triangles are tested without a tree: they must not get the task kernels
              # (whose workspace sits behind a tree staged in LDS), whatever the hook asks for
-             (scenes.soup(8, 1, seed=6, size=0.9), 0), (scenes.soup(6, 0, seed=3, size=0.9), 1)]
+             (scenes.soup(8, 1, seed=6, size=0.9), 0), (scenes.soup(6, 0, seed=3, size=0.9), 1),
+             # around the 32 leaves the task kernels take (a quad makes a leaf of two, every tenth quad comes twice):
+             # 30 to 33 quads, the last ones left to the walk
+             (scenes.quad_soup(27, seed=5, size=0.8), 1), (scenes.quad_soup(28, seed=7, size=0.8), 1),
+             (scenes.quad_soup(29, seed=8, size=0.8), 0), (scenes.quad_soup(30, seed=2, size=0.8), 1)]
     for sc, sky in cases:
         for kw in (dict(width=200, height=120, sky=sky, pool_paths=1 << 13),
                    dict(width=97, height=61, sky=sky, pool_paths=700, max_bounces=4, camera=2)):
